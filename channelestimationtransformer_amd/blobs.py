@@ -1,0 +1,157 @@
+"""Flattening of reference-style state_dicts into the fp32 blobs the C ABI takes.
+
+The order is the one documented next to `cet_informer_blob_size` / `cet_rnn_blob_size` in
+include/cet.h. All tensors keep their PyTorch layout; any re-packing for the kernels happens
+inside the library.
+"""
+import numpy as np
+
+from ._cabi import InformerCfg
+
+RNN_KINDS = {"rnn": 0, "gru": 1, "lstm": 2}
+RNN_GATES = {0: 1, 1: 3, 2: 4}
+
+
+def normalize_state_dict(sd):
+    """Accepts the three on-disk conventions of the reference's checkpoints.
+
+    `{'state_dict': ...}` wrapper (LocalSimulations/Predict.py:90-91), bare dict with the
+    `module.` prefix DataParallel adds (HPC/python/Evaluate.py:71-73), bare dict without
+    prefix (HPC/python/Evaluate.py:78-79).
+    """
+    if "state_dict" in sd and not hasattr(sd["state_dict"], "shape"):
+        sd = sd["state_dict"]
+    out = {}
+    for k, v in sd.items():
+        out[k[7:] if k.startswith("module.") else k] = v
+    return out
+
+
+def _np(t):
+    if hasattr(t, "detach"):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+def encoder_depths(e_layers, stack):
+    """Layer counts of the encoders: `list(range(e_layers, 2, -1))` for the stacked models
+    (LocalSimulations/models/model.py:178), one encoder otherwise."""
+    return list(range(e_layers, 2, -1)) if stack else [e_layers]
+
+
+def make_informer_cfg(enc_in, dec_in, c_out, seq_len, label_len, out_len, d_model, n_heads,
+                      e_layers, d_layers, d_ff, stack, distil, activation):
+    return InformerCfg(enc_in=enc_in, dec_in=dec_in, c_out=c_out, seq_len=seq_len,
+                       label_len=label_len, pred_len=out_len, d_model=d_model,
+                       n_heads=n_heads, e_layers=e_layers, d_layers=d_layers, d_ff=d_ff,
+                       stack=int(bool(stack)), distil=int(bool(distil)),
+                       activation=0 if activation == "relu" else 1)
+
+
+def pack_informer(sd, cfg):
+    """state_dict (reference key names) -> 1-D float32 array in the C ABI's order."""
+    sd = normalize_state_dict(sd)
+    parts = []
+
+    def put(key, shape=None):
+        a = _np(sd[key])
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{key}: shape {tuple(a.shape)} != expected {tuple(shape)}")
+        parts.append(a.reshape(-1))
+
+    D, F = cfg.d_model, cfg.d_ff
+    for emb, cin, L in (("enc_embedding", cfg.enc_in, cfg.seq_len),
+                        ("dec_embedding", cfg.dec_in, cfg.label_len + cfg.pred_len)):
+        put(f"{emb}.value_embedding.tokenConv.weight", (D, cin, 3))
+        put(f"{emb}.value_embedding.tokenConv.bias", (D,))
+        pe = _np(sd[f"{emb}.position_embedding.pe"])
+        parts.append(np.ascontiguousarray(pe.reshape(-1, D)[:L]).reshape(-1))
+
+    def put_attn(prefix):
+        for proj in ("query", "key", "value", "out"):
+            put(f"{prefix}.{proj}_projection.weight", (D, D))
+            put(f"{prefix}.{proj}_projection.bias", (D,))
+
+    def put_ffn(prefix):
+        # Conv1d(kernel_size=1) weights are [out, in, 1]
+        put(f"{prefix}.conv1.weight", (F, D, 1))
+        put(f"{prefix}.conv1.bias", (F,))
+        put(f"{prefix}.conv2.weight", (D, F, 1))
+        put(f"{prefix}.conv2.bias", (D,))
+
+    depths = encoder_depths(cfg.e_layers, cfg.stack)
+    for ei, el in enumerate(depths):
+        enc = f"encoder.encoders.{ei}" if cfg.stack else "encoder"
+        for l in range(el):
+            p = f"{enc}.attn_layers.{l}"
+            put_attn(f"{p}.attention")
+            put_ffn(p)
+            for n in ("norm1", "norm2"):
+                put(f"{p}.{n}.weight", (D,))
+                put(f"{p}.{n}.bias", (D,))
+        if cfg.distil:
+            for l in range(el - 1):
+                p = f"{enc}.conv_layers.{l}"
+                put(f"{p}.downConv.weight", (D, D, 3))
+                put(f"{p}.downConv.bias", (D,))
+                for n in ("weight", "bias", "running_mean", "running_var"):
+                    put(f"{p}.norm.{n}", (D,))
+        put(f"{enc}.norm.weight", (D,))
+        put(f"{enc}.norm.bias", (D,))
+    for l in range(cfg.d_layers):
+        p = f"decoder.layers.{l}"
+        put_attn(f"{p}.self_attention")
+        put_attn(f"{p}.cross_attention")
+        put_ffn(p)
+        for n in ("norm1", "norm2", "norm3"):
+            put(f"{p}.{n}.weight", (D,))
+            put(f"{p}.{n}.bias", (D,))
+    put("decoder.norm.weight", (D,))
+    put("decoder.norm.bias", (D,))
+    put("projection.weight", (cfg.c_out, D))
+    put("projection.bias", (cfg.c_out,))
+    return np.concatenate(parts)
+
+
+def informer_blob_len(cfg):
+    """Host-side recomputation of `cet_informer_blob_size` (cross-checked in the tests)."""
+    D, F = cfg.d_model, cfg.d_ff
+    n = D * cfg.enc_in * 3 + D + cfg.seq_len * D
+    n += D * cfg.dec_in * 3 + D + (cfg.label_len + cfg.pred_len) * D
+    attn = 4 * (D * D + D)
+    ffn = F * D + F + D * F + D
+    for el in encoder_depths(cfg.e_layers, cfg.stack):
+        n += el * (attn + ffn + 4 * D)
+        if cfg.distil:
+            n += (el - 1) * (3 * D * D + D + 4 * D)
+        n += 2 * D
+    n += cfg.d_layers * (2 * attn + ffn + 6 * D)
+    n += 2 * D + cfg.c_out * D + cfg.c_out
+    return n
+
+
+def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers):
+    """state_dict of RNN/GRU/LSTM (keys `model.encoder.0.*`, `model.<cell>.weight_ih_l0` ...)
+    -> 1-D float32 array in the C ABI's order."""
+    sd = normalize_state_dict(sd)
+    cell = {0: "rnn", 1: "gru", 2: "lstm"}[kind]
+    G = RNN_GATES[kind]
+    parts = []
+
+    def put(key, shape):
+        a = _np(sd[key])
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{key}: shape {tuple(a.shape)} != expected {tuple(shape)}")
+        parts.append(a.reshape(-1))
+
+    put("model.encoder.0.weight", (input_size, features))
+    put("model.encoder.0.bias", (input_size,))
+    for l in range(num_layers):
+        inp = input_size if l == 0 else hidden_size
+        put(f"model.{cell}.weight_ih_l{l}", (G * hidden_size, inp))
+        put(f"model.{cell}.weight_hh_l{l}", (G * hidden_size, hidden_size))
+        put(f"model.{cell}.bias_ih_l{l}", (G * hidden_size,))
+        put(f"model.{cell}.bias_hh_l{l}", (G * hidden_size,))
+    put("model.decoder.0.weight", (features, hidden_size))
+    put("model.decoder.0.bias", (features,))
+    return np.concatenate(parts)

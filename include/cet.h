@@ -1,0 +1,154 @@
+/*
+ * cet.h -- C ABI of libcet.so: MI355X (gfx950) channel-predictor + LMMSE inference path.
+ *
+ * Every entry point takes plain pointers and sizes. Device buffers are owned by the
+ * caller; the library only owns the weights held inside a handle. Kernels are enqueued
+ * on the HIP stream passed in (`stream` is a hipStream_t cast to void*, NULL = default
+ * stream) and the calls do not synchronise. Return value: 0 on success, a CET_ERR_* code
+ * otherwise (never an exception across this boundary).
+ *
+ * The reference has no FFI of its own (it is a pure-Python PyTorch/Sionna program), so each
+ * entry point below names the Python call it stands in for.
+ */
+#ifndef CET_H
+#define CET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  CET_OK = 0,
+  CET_ERR_INVALID_ARG = 1, /* null pointer, negative size, bad enum value                */
+  CET_ERR_UNSUPPORTED = 2, /* well-formed request outside what the kernels are built for */
+  CET_ERR_HIP = 3,         /* a HIP runtime call failed; see cet_last_hip_error()         */
+  CET_ERR_ALLOC = 4,       /* host or device allocation failed                           */
+  CET_ERR_BLOB_SIZE = 5    /* weight blob length does not match the configuration        */
+};
+
+typedef struct cet_handle_s* cet_handle;
+
+/* Library / device ------------------------------------------------------------------ */
+
+/* Text for a CET_ERR_* code (static storage). */
+const char* cet_strerror(int code);
+/* hipError_t value of the most recent failing HIP call on this thread (0 if none). */
+int cet_last_hip_error(void);
+/* ABI version, bumped when a signature changes. */
+int cet_abi_version(void);
+/* Releases the device weights and the handle (models and recurrent nets alike). */
+int cet_destroy(cet_handle h);
+
+/* Transformer predictor -------------------------------------------------------------- */
+
+/* Constructor arguments of Informer / InformerStack / InformerStack_e2e
+ * (LocalSimulations/models/model.py:12-16, 85-89, 161-165). `attn` is always 'full',
+ * `embed` always 'fixed'; dropout is inactive in eval mode and has no field. */
+typedef struct cet_informer_cfg {
+  int32_t enc_in, dec_in, c_out;
+  int32_t seq_len, label_len, pred_len;
+  int32_t d_model, n_heads, e_layers, d_layers, d_ff;
+  int32_t stack;      /* 0: Informer (one encoder). 1: InformerStack / InformerStack_e2e */
+  int32_t distil;     /* 1: ConvLayer between encoder layers (encoder.py:5-23)           */
+  int32_t activation; /* 0 relu, 1 gelu (exact erf form)                                 */
+} cet_informer_cfg;
+
+/* Number of fp32 values cet_informer_create expects for `cfg` (0 if cfg is unsupported).
+ *
+ * Blob order (all tensors in their PyTorch layout, row-major, concatenated):
+ *   enc_embedding : tokenConv.weight[d_model,enc_in,3], tokenConv.bias[d_model],
+ *                   pe[0:seq_len, d_model]
+ *   dec_embedding : tokenConv.weight[d_model,dec_in,3], tokenConv.bias[d_model],
+ *                   pe[0:label_len+pred_len, d_model]
+ *   for each encoder of the stack (stack=1: e_layers, e_layers-1, ... 3 layers; stack=0: one
+ *   encoder of e_layers layers):
+ *       for each attention layer: query/key/value/out projection weight[d_model,d_model]
+ *           + bias[d_model] (4 pairs), conv1.weight[d_ff,d_model], conv1.bias[d_ff],
+ *           conv2.weight[d_model,d_ff], conv2.bias[d_model], norm1.weight, norm1.bias,
+ *           norm2.weight, norm2.bias
+ *       then, if distil, for each of the (layers-1) ConvLayers: downConv.weight[d_model,
+ *           d_model,3], downConv.bias, norm.weight, norm.bias, norm.running_mean,
+ *           norm.running_var
+ *       then norm.weight, norm.bias
+ *   for each decoder layer: self_attention q/k/v/out (weight,bias), cross_attention
+ *       q/k/v/out (weight,bias), conv1 (w,b), conv2 (w,b), norm1, norm2, norm3 (w,b each)
+ *   decoder.norm.weight, decoder.norm.bias, projection.weight[c_out,d_model],
+ *   projection.bias[c_out]
+ */
+size_t cet_informer_blob_size(const cet_informer_cfg* cfg);
+
+/* Stands in for `InformerStack(...)` + `load_state_dict` + `.eval()` + `.to(device)`
+ * (LocalSimulations/Predict.py:44-64, 90-94). `weights` is a HOST pointer; the packed copy
+ * lives on the current HIP device. */
+int cet_informer_create(const cet_informer_cfg* cfg, const float* weights, size_t n_weights,
+                        cet_handle* out);
+
+/* Number of fp32 values of the attention-map buffer for batch B: the encoder self-attention
+ * maps [B, n_heads, L, L] of every encoder layer, concatenated in execution order. */
+size_t cet_informer_attn_size(cet_handle h, int B);
+
+/* Stands in for `informer(enc_inp, dec_inp)` (LocalSimulations/models/model.py:220-234,
+ * call site Predict.py:114). Device pointers:
+ *   x_enc [B, seq_len, enc_in], x_dec [B, label_len+pred_len, dec_in],
+ *   out   [B, pred_len, c_out],
+ *   attn  NULL, or cet_informer_attn_size(h,B) floats (what output_attention=True returns). */
+int cet_informer_forward(cet_handle h, const float* x_enc, const float* x_dec, float* out,
+                         float* attn, int B, void* stream);
+
+/* Debug variant: additionally copies the activations after every stage into `taps`
+ * (device, cet_informer_taps_size(h,B) floats; layout [stage][B][rows_of_stage][d_model]). */
+size_t cet_informer_taps_size(cet_handle h, int B);
+int cet_informer_forward_taps(cet_handle h, const float* x_enc, const float* x_dec, float* out,
+                              float* attn, float* taps, int B, void* stream);
+
+/* Recurrent predictors ---------------------------------------------------------------- */
+
+enum { CET_RNN_TANH = 0, CET_RNN_GRU = 1, CET_RNN_LSTM = 2 };
+
+/* fp32 count expected by cet_rnn_create. Blob order (PyTorch layouts):
+ *   model.encoder.0.weight[input,features], model.encoder.0.bias[input],
+ *   for l in 0..layers-1: weight_ih_l[G*hidden, in_l], weight_hh_l[G*hidden, hidden],
+ *                         bias_ih_l[G*hidden], bias_hh_l[G*hidden]
+ *                         (G = 1 / 3 / 4 for RNN / GRU / LSTM; in_0 = input, else hidden)
+ *   model.decoder.0.weight[features,hidden], model.decoder.0.bias[features] */
+size_t cet_rnn_blob_size(int kind, int features, int input_size, int hidden_size,
+                         int num_layers);
+
+/* Stands in for `GRU/LSTM/RNN(features, input_size, hidden_size, num_layers)` +
+ * `load_state_dict` + `.eval()` (LocalSimulations/models/model.py:276, 350, 426;
+ * HPC/python/Evaluate.py:60-98). `weights` is a HOST pointer. */
+int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int num_layers,
+                   const float* weights, size_t n_weights, cet_handle* out);
+
+/* Stands in for `model.test_data(x, pred_len, device)` (LocalSimulations/models/model.py:
+ * 298-312, 373-388, 449-465): zero initial state, seq_len teacher-forced steps on x, then
+ * pred_len-1 closed-loop steps on the model's own output. Device pointers:
+ *   x [B, seq_len, features], out [B, pred_len, features]. */
+int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len,
+                    int pred_len, void* stream);
+
+/* LMMSE MIMO equalizer ---------------------------------------------------------------- */
+
+enum {
+  CET_NO_SCALAR = 0,    /* one noise variance for all resource elements (`no_scalar`)      */
+  CET_NO_PER_RE = 1,    /* no_dev[N]     : noise variance per resource element             */
+  CET_NO_PER_RE_RX = 2  /* no_dev[N,Nr]  : diagonal noise+interference covariance per RE   */
+};
+
+/* Stands in for the per-resource-element arithmetic of Sionna's
+ * `LMMSEEqualizer(rg, sm)([y, h_hat, err_var, no])` (call sites
+ * LocalSimulations/EndtoEndtest.py:133,191; HPC/python/EvaluateE2E.py:254,317):
+ *   G = (H^H S^-1 H + I)^-1 H^H S^-1,  x_hat = diag(GH)^-1 G y,  no_eff = Re(1/diag(GH) - 1)
+ * with S diagonal. Device pointers, interleaved (re,im) float32:
+ *   y [N,Nr,2], H [N,Nr,Ns,2]  ->  x_hat [N,Ns,2], no_eff [N,Ns].
+ * Supported (Nr,Ns): Nr in {2,4,8,16}, Ns in {1,2,4}, Ns <= Nr. */
+int cet_lmmse(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+              float* x_hat, float* no_eff, long N, int Nr, int Ns, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CET_H */
