@@ -1,0 +1,173 @@
+// C ABI of libcet.so (declared in include/cet.h): argument validation, status codes and the
+// handle type. The kernels and their launchers live in lmmse.hip, informer.hip and rnn.hip.
+#include <new>
+
+#include "cet_internal.h"
+
+namespace cet {
+
+static thread_local int g_last_hip_error = 0;
+
+int hip_fail(hipError_t e) {
+  g_last_hip_error = (int)e;
+  (void)hipGetLastError();  // clear the sticky error so later calls start clean
+  return e == hipErrorOutOfMemory ? CET_ERR_ALLOC : CET_ERR_HIP;
+}
+
+// implemented in informer.hip / rnn.hip
+size_t informer_blob_size(const cet_informer_cfg* cfg);
+int informer_create(const cet_informer_cfg* cfg, const float* w, size_t n, InformerModel** out);
+void informer_destroy(InformerModel* m);
+size_t informer_attn_size(const InformerModel* m, int B);
+size_t informer_taps_size(const InformerModel* m, int B);
+int informer_forward(const InformerModel* m, const float* x_enc, const float* x_dec, float* out,
+                     float* attn, float* taps, int B, hipStream_t stream);
+
+size_t rnn_blob_size(int kind, int F, int I, int H, int layers);
+int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t n, RnnModel** out);
+void rnn_destroy(RnnModel* m);
+int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                hipStream_t stream);
+
+}  // namespace cet
+
+using namespace cet;
+
+extern "C" {
+
+const char* cet_strerror(int code) {
+  switch (code) {
+    case CET_OK: return "success";
+    case CET_ERR_INVALID_ARG: return "invalid argument";
+    case CET_ERR_UNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+    case CET_ERR_HIP: return "HIP runtime call failed";
+    case CET_ERR_ALLOC: return "allocation failed";
+    case CET_ERR_BLOB_SIZE: return "weight blob length does not match the configuration";
+    default: return "unknown error code";
+  }
+}
+
+int cet_last_hip_error(void) { return g_last_hip_error; }
+
+int cet_abi_version(void) { return 1; }
+
+int cet_destroy(cet_handle h) {
+  if (!h) return CET_ERR_INVALID_ARG;
+  if (h->kind == HANDLE_INFORMER) {
+    informer_destroy(static_cast<InformerModel*>(h->impl));
+  } else if (h->kind == HANDLE_RNN) {
+    rnn_destroy(static_cast<RnnModel*>(h->impl));
+  } else {
+    return CET_ERR_INVALID_ARG;
+  }
+  h->kind = 0;
+  delete h;
+  return CET_OK;
+}
+
+size_t cet_informer_blob_size(const cet_informer_cfg* cfg) {
+  return cfg ? informer_blob_size(cfg) : 0;
+}
+
+int cet_informer_create(const cet_informer_cfg* cfg, const float* weights, size_t n_weights,
+                        cet_handle* out) {
+  if (!cfg || !weights || !out) return CET_ERR_INVALID_ARG;
+  InformerModel* m = nullptr;
+  const int rc = informer_create(cfg, weights, n_weights, &m);
+  if (rc != CET_OK) return rc;
+  cet_handle h = new (std::nothrow) cet_handle_s;
+  if (!h) {
+    informer_destroy(m);
+    return CET_ERR_ALLOC;
+  }
+  h->kind = HANDLE_INFORMER;
+  h->impl = m;
+  (void)hipGetDevice(&h->device);
+  *out = h;
+  return CET_OK;
+}
+
+size_t cet_informer_attn_size(cet_handle h, int B) {
+  if (!h || h->kind != HANDLE_INFORMER || B < 0) return 0;
+  return informer_attn_size(static_cast<InformerModel*>(h->impl), B);
+}
+
+size_t cet_informer_taps_size(cet_handle h, int B) {
+  if (!h || h->kind != HANDLE_INFORMER || B < 0) return 0;
+  return informer_taps_size(static_cast<InformerModel*>(h->impl), B);
+}
+
+int cet_informer_forward_taps(cet_handle h, const float* x_enc, const float* x_dec, float* out,
+                              float* attn, float* taps, int B, void* stream) {
+  if (!h || h->kind != HANDLE_INFORMER || B < 0) return CET_ERR_INVALID_ARG;
+  if (B == 0) return CET_OK;
+  if (!x_enc || !x_dec || !out) return CET_ERR_INVALID_ARG;
+  return informer_forward(static_cast<InformerModel*>(h->impl), x_enc, x_dec, out, attn, taps, B,
+                          static_cast<hipStream_t>(stream));
+}
+
+int cet_informer_forward(cet_handle h, const float* x_enc, const float* x_dec, float* out,
+                         float* attn, int B, void* stream) {
+  return cet_informer_forward_taps(h, x_enc, x_dec, out, attn, nullptr, B, stream);
+}
+
+size_t cet_rnn_blob_size(int kind, int features, int input_size, int hidden_size,
+                         int num_layers) {
+  return rnn_blob_size(kind, features, input_size, hidden_size, num_layers);
+}
+
+int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int num_layers,
+                   const float* weights, size_t n_weights, cet_handle* out) {
+  if (!weights || !out) return CET_ERR_INVALID_ARG;
+  RnnModel* m = nullptr;
+  const int rc = rnn_create(kind, features, input_size, hidden_size, num_layers, weights,
+                            n_weights, &m);
+  if (rc != CET_OK) return rc;
+  cet_handle h = new (std::nothrow) cet_handle_s;
+  if (!h) {
+    rnn_destroy(m);
+    return CET_ERR_ALLOC;
+  }
+  h->kind = HANDLE_RNN;
+  h->impl = m;
+  (void)hipGetDevice(&h->device);
+  *out = h;
+  return CET_OK;
+}
+
+int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len, int pred_len,
+                    void* stream) {
+  if (!h || h->kind != HANDLE_RNN || B < 0 || seq_len < 1 || pred_len < 1)
+    return CET_ERR_INVALID_ARG;
+  if (B == 0) return CET_OK;
+  if (!x || !out) return CET_ERR_INVALID_ARG;
+  return rnn_rollout(static_cast<RnnModel*>(h->impl), x, out, B, seq_len, pred_len,
+                     static_cast<hipStream_t>(stream));
+}
+
+static int lmmse_checked(const float* y, const float* H, int no_mode, float no_scalar,
+                         const float* no_dev, float* x_hat, float* no_eff, long N, int Nr, int Ns,
+                         int variant, void* stream) {
+  if (N < 0 || Nr <= 0 || Ns <= 0) return CET_ERR_INVALID_ARG;
+  if (no_mode < CET_NO_SCALAR || no_mode > CET_NO_PER_RE_RX) return CET_ERR_INVALID_ARG;
+  if (N == 0) return CET_OK;
+  if (!y || !H || !x_hat || !no_eff) return CET_ERR_INVALID_ARG;
+  if (no_mode != CET_NO_SCALAR && !no_dev) return CET_ERR_INVALID_ARG;
+  if (no_mode == CET_NO_SCALAR && !(no_scalar > 0.f)) return CET_ERR_INVALID_ARG;
+  if (Ns > Nr) return CET_ERR_UNSUPPORTED;
+  return lmmse_launch(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, variant,
+                      static_cast<hipStream_t>(stream));
+}
+
+int cet_lmmse(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+              float* x_hat, float* no_eff, long N, int Nr, int Ns, void* stream) {
+  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, 0, stream);
+}
+
+int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scalar,
+                     const float* no_dev, float* x_hat, float* no_eff, long N, int Nr, int Ns,
+                     void* stream) {
+  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, 1, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// Internal declarations shared by the translation units of libcet.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/cet.h"
+
+namespace cet {
+
+// Records a failing hipError_t for cet_last_hip_error() and maps it to CET_ERR_HIP.
+int hip_fail(hipError_t e);
+
+#define CET_HIP(call)                                 \
+  do {                                                \
+    hipError_t _e = (call);                           \
+    if (_e != hipSuccess) return ::cet::hip_fail(_e); \
+  } while (0)
+
+enum HandleKind { HANDLE_INFORMER = 0x1F0, HANDLE_RNN = 0x2F0 };
+
+struct InformerModel;
+struct RnnModel;
+
+// launchers implemented next to their kernels
+int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+                 float* x_hat, float* no_eff, long N, int Nr, int Ns, int variant,
+                 hipStream_t stream);
+
+}  // namespace cet
+
+struct cet_handle_s {
+  int kind;
+  int device;
+  void* impl;
+};

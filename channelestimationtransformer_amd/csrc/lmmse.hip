@@ -1,0 +1,473 @@
+// LMMSE MIMO equalizer for gfx950: per resource element (RE)
+//     A = H^H S^-1 H + I,  z = A^-1 H^H S^-1 y,  d = diag(A^-1 H^H S^-1 H),
+//     x_hat = z / d,  no_eff = 1/d - 1
+// (the arithmetic behind `lmmse_equ([y, h_hat, err_var, no])`,
+// LocalSimulations/EndtoEndtest.py:133,191).
+//
+// The job is HBM-bound (688 B and ~2.9 kFLOP per RE at 16x4), so the kernel is built around
+// the memory stream, not around the arithmetic:
+//   * each wave owns a tile of T consecutive REs; H and y of the NEXT tile are pulled
+//     global->LDS by LDS-DMA (global_load_lds, 16 B/lane, 1 KiB per wave instruction, fully
+//     coalesced) while the wave does the arithmetic of the current tile from LDS;
+//   * the only synchronisation is the wave's own counted s_waitcnt vmcnt(N): tiles are
+//     wave-private, there is no workgroup barrier;
+//   * in LDS the 16-byte chunks of each RE are XOR-permuted (done on the DMA *source*
+//     address, the LDS side stays linear) so that the per-RE strided ds_read_b128 of the
+//     compute phase are bank-conflict free;
+//   * one RE is handled by LPR lanes that split the receive antennas; the partial Gram
+//     matrices are combined with cross-lane adds and every lane then carries out the small
+//     Hermitian solve (Cholesky, triangular inverse) in registers.
+// With S = no*I the kernel uses A' = H^H H + no*I, for which d = 1 - no*(A'^-1)_ss and
+// no_eff = t/(1-t), t = no*(A'^-1)_ss: no cancellation in no_eff at high SNR.
+#include "cet_internal.h"
+
+namespace cet {
+namespace {
+
+constexpr int pair_index(int ns, int s, int s2) { return s * ns - s * (s + 1) / 2 + (s2 - s - 1); }
+
+template <int NS>
+struct Gram {
+  static constexpr int NP = NS * (NS - 1) / 2 > 0 ? NS * (NS - 1) / 2 : 1;
+  float diag[NS];          // sum |h_s|^2
+  float offr[NP], offi[NP];  // s < s2: sum conj(h_s) h_s2
+  float br[NS], bi[NS];    // sum conj(h_s) y
+  __device__ inline void clear() {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) diag[s] = br[s] = bi[s] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) offr[i] = offi[i] = 0.f;
+  }
+};
+
+// One receive antenna's contribution. WEIGHTED: row scaled by w = 1/S_r (diagonal S).
+template <int NS, bool WEIGHTED>
+__device__ inline void gram_row(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS],
+                                float yr, float yi, float w) {
+  float ar[NS], ai[NS];  // (weighted) conj-side operand
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    ar[s] = WEIGHTED ? hr[s] * w : hr[s];
+    ai[s] = WEIGHTED ? hi[s] * w : hi[s];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    g.diag[s] = fmaf(ar[s], hr[s], g.diag[s]);
+    g.diag[s] = fmaf(ai[s], hi[s], g.diag[s]);
+    g.br[s] = fmaf(ar[s], yr, g.br[s]);
+    g.br[s] = fmaf(ai[s], yi, g.br[s]);
+    g.bi[s] = fmaf(ar[s], yi, g.bi[s]);
+    g.bi[s] = fmaf(-ai[s], yr, g.bi[s]);
+#pragma unroll
+    for (int s2 = s + 1; s2 < NS; ++s2) {
+      const int p = pair_index(NS, s, s2);
+      g.offr[p] = fmaf(ar[s], hr[s2], g.offr[p]);
+      g.offr[p] = fmaf(ai[s], hi[s2], g.offr[p]);
+      g.offi[p] = fmaf(ar[s], hi[s2], g.offi[p]);
+      g.offi[p] = fmaf(-ai[s], hr[s2], g.offi[p]);
+    }
+  }
+}
+
+// Solves (G + lam*I) z = b by Cholesky and forms x_hat / no_eff (see the file header).
+template <int NS>
+__device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS],
+                                   float (&xi)[NS], float (&ne)[NS]) {
+  float Lr[NS][NS], Li[NS][NS], inv[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    float d = g.diag[j] + lam;
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= Lr[j][k] * Lr[j][k] + Li[j][k] * Li[j][k];
+    const float ljj = sqrtf(d);
+    inv[j] = 1.0f / ljj;
+    Lr[j][j] = ljj;
+    Li[j][j] = 0.f;
+#pragma unroll
+    for (int i = j + 1; i < NS; ++i) {
+      const int p = pair_index(NS, j, i);
+      float sr = g.offr[p], si = -g.offi[p];  // A_ij = conj(A_ji), i > j
+#pragma unroll
+      for (int k = 0; k < j; ++k) {
+        sr -= Lr[i][k] * Lr[j][k] + Li[i][k] * Li[j][k];
+        si -= Li[i][k] * Lr[j][k] - Lr[i][k] * Li[j][k];
+      }
+      Lr[i][j] = sr * inv[j];
+      Li[i][j] = si * inv[j];
+    }
+  }
+  // W = L^-1 (lower triangular)
+  float Wr[NS][NS], Wi[NS][NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    Wr[j][j] = inv[j];
+    Wi[j][j] = 0.f;
+#pragma unroll
+    for (int i = j + 1; i < NS; ++i) {
+      float sr = 0.f, si = 0.f;
+#pragma unroll
+      for (int k = j; k < i; ++k) {
+        sr += Lr[i][k] * Wr[k][j] - Li[i][k] * Wi[k][j];
+        si += Lr[i][k] * Wi[k][j] + Li[i][k] * Wr[k][j];
+      }
+      Wr[i][j] = -sr * inv[i];
+      Wi[i][j] = -si * inv[i];
+    }
+  }
+  // u = W b
+  float ur[NS], ui[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      sr += Wr[i][j] * g.br[j] - Wi[i][j] * g.bi[j];
+      si += Wr[i][j] * g.bi[j] + Wi[i][j] * g.br[j];
+    }
+    ur[i] = sr;
+    ui[i] = si;
+  }
+  // z = W^H u ; (A^-1)_ss = sum_k |W_ks|^2
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float zr = 0.f, zi = 0.f, a = 0.f;
+#pragma unroll
+    for (int k = s; k < NS; ++k) {
+      zr += Wr[k][s] * ur[k] + Wi[k][s] * ui[k];
+      zi += Wr[k][s] * ui[k] - Wi[k][s] * ur[k];
+      a += Wr[k][s] * Wr[k][s] + Wi[k][s] * Wi[k][s];
+    }
+    const float t = lam * a;
+    const float rd = 1.0f / (1.0f - t);
+    xr[s] = zr * rd;
+    xi[s] = zi * rd;
+    ne[s] = t * rd;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Straightforward kernel: one RE per thread, operands read straight from global memory.
+// Serves every noise mode and is what the tiled kernel is cross-checked against.
+template <int NR, int NS, int MODE>
+__global__ __launch_bounds__(256) void lmmse_direct(const float* __restrict__ y,
+                                                    const float* __restrict__ H, float no_scalar,
+                                                    const float* __restrict__ no_dev,
+                                                    float* __restrict__ x_hat,
+                                                    float* __restrict__ no_eff, long N) {
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  Gram<NS> g;
+  g.clear();
+  const float2* h2 = reinterpret_cast<const float2*>(H) + n * (NR * NS);
+  const float2* y2 = reinterpret_cast<const float2*>(y) + n * NR;
+  for (int r = 0; r < NR; ++r) {
+    float hr[NS], hi[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float2 v = h2[r * NS + s];
+      hr[s] = v.x;
+      hi[s] = v.y;
+    }
+    const float2 yv = y2[r];
+    if (MODE == CET_NO_PER_RE_RX) {
+      gram_row<NS, true>(g, hr, hi, yv.x, yv.y, 1.0f / no_dev[n * NR + r]);
+    } else {
+      gram_row<NS, false>(g, hr, hi, yv.x, yv.y, 1.0f);
+    }
+  }
+  const float lam = MODE == CET_NO_SCALAR ? no_scalar : (MODE == CET_NO_PER_RE ? no_dev[n] : 1.0f);
+  float xr[NS], xi[NS], ne[NS];
+  lmmse_solve<NS>(g, lam, xr, xi, ne);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    reinterpret_cast<float2*>(x_hat)[n * NS + s] = make_float2(xr[s], xi[s]);
+    no_eff[n * NS + s] = ne[s];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Tiled, LDS-DMA fed kernel (noise modes: scalar, per RE).
+
+// LDS-DMA: each lane supplies its own 16-byte (or 4-byte) global source; the wave's data lands
+// at lds_addr + lane*size. Issued through inline asm on purpose: hipcc orders every ds_read
+// behind an LDS-DMA it knows about with s_waitcnt vmcnt(0), which would drain the prefetch
+// of the next tile before the current one is computed. Hidden from the compiler, the DMA is
+// ordered only by the counted waits below. M0 carries the LDS byte address and is restored.
+__device__ inline unsigned lds_address(const void* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ inline void dma16(const void* src, unsigned lds_addr_wave_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_addr_wave_uniform)
+      : "memory");
+}
+__device__ inline void dma4(const void* src, unsigned lds_addr_wave_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_addr_wave_uniform)
+      : "memory");
+}
+
+// XOR applied to the chunk index of RE `t` (CH 16-byte chunks per RE): makes the 16 lanes of
+// a ds_read_b128 lane group, which read the same chunk of 16 different REs, hit 16 different
+// 16-byte bank slots.
+template <int CH>
+__device__ inline int chunk_swizzle(int t) {
+  if (CH >= 16) return t & 15;
+  if (CH == 8) return (t >> 1) & 7;
+  if (CH == 4) return (t >> 2) & 3;
+  if (CH == 2) return (t >> 3) & 1;
+  return 0;
+}
+
+template <int N>
+__device__ inline void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NR, int NS, int LPR, bool PER_RE_NOISE>
+__global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
+                                                  const float* __restrict__ H, float no_scalar,
+                                                  const float* __restrict__ no_dev,
+                                                  float* __restrict__ x_hat,
+                                                  float* __restrict__ no_eff, long N,
+                                                  long n_tiles) {
+  constexpr int T = 64 / LPR;             // REs per tile
+  constexpr int HB = NR * NS * 8;         // bytes of H per RE
+  constexpr int YB = NR * 8;              // bytes of y per RE
+  constexpr int CH = HB / 16, CY = YB / 16;
+  constexpr int H_TILE = T * HB, Y_TILE = T * YB;
+  constexpr int H_INSTR = H_TILE / 1024, Y_INSTR = Y_TILE / 1024;
+  constexpr int NO_INSTR = PER_RE_NOISE ? 1 : 0;
+  constexpr int NO_TILE = PER_RE_NOISE ? 256 : 0;  // T floats, padded to one DMA instruction
+  constexpr int BUF = H_TILE + Y_TILE + NO_TILE;
+  constexpr int RPP = NR / LPR;           // receive antennas per lane
+  static_assert(H_TILE % 1024 == 0 && Y_TILE % 1024 == 0, "tiles are whole DMA instructions");
+  static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
+  static_assert((CH & (CH - 1)) == 0 && (CY & (CY - 1)) == 0, "power-of-two chunk counts");
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+  const int lane = threadIdx.x;
+  const int t = lane & (T - 1);  // RE within the tile
+  const int p = lane / T;        // which slice of the receive antennas
+
+  // Byte offsets of this lane's DMA sources inside a tile: the same for every tile.
+  unsigned hoff[H_INSTR], yoff[Y_INSTR];
+#pragma unroll
+  for (int i = 0; i < H_INSTR; ++i) {
+    const int P = i * 64 + lane;  // LDS chunk position written by this lane
+    const int tt = P / CH, q = P % CH;
+    hoff[i] = tt * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < Y_INSTR; ++i) {
+    const int P = i * 64 + lane;
+    const int tt = P / CY, q = P % CY;
+    yoff[i] = tt * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4);
+  }
+
+  auto fill = [&](int buf, long tile) {
+    const long re0 = tile * T;
+    const unsigned hdst = lds_address(smem) + buf * BUF;
+    const unsigned ydst = hdst + H_TILE;
+    const char* hb = reinterpret_cast<const char*>(H) + re0 * HB;
+    const char* yb = reinterpret_cast<const char*>(y) + re0 * YB;
+    // A tail tile re-reads the last RE for the missing ones (results are discarded).
+    const long last = N - 1 - re0;  // >= T-1 for a full tile
+#pragma unroll
+    for (int i = 0; i < H_INSTR; ++i) {
+      unsigned off = hoff[i];
+      if (last < T - 1) {
+        const long tt = (i * 64 + lane) / CH;
+        if (tt > last) off -= (unsigned)(tt - last) * HB;
+      }
+      dma16(hb + off, hdst + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < Y_INSTR; ++i) {
+      unsigned off = yoff[i];
+      if (last < T - 1) {
+        const long tt = (i * 64 + lane) / CY;
+        if (tt > last) off -= (unsigned)(tt - last) * YB;
+      }
+      dma16(yb + off, ydst + i * 1024);
+    }
+    if (PER_RE_NOISE) {
+      long re = re0 + (lane & (T - 1));
+      re = re < N ? re : N - 1;
+      dma4(no_dev + re, ydst + Y_TILE);
+    }
+  };
+
+  auto compute = [&](int buf, long tile) {
+    const char* hsrc = smem + buf * BUF + t * HB;
+    const char* ysrc = smem + buf * BUF + H_TILE + t * YB;
+    const int swh = chunk_swizzle<CH>(t), swy = chunk_swizzle<CY>(t);
+    Gram<NS> g;
+    g.clear();
+#pragma unroll
+    for (int rr = 0; rr < RPP; rr += 2) {
+      // y of antennas r, r+1 (one 16-byte chunk)
+      const int r = p * RPP + rr;
+      const float4 yv = *reinterpret_cast<const float4*>(ysrc + (((r >> 1) ^ swy) << 4));
+      float hr[2][NS], hi[2][NS];
+      if (NS == 1) {
+        const float4 hv = *reinterpret_cast<const float4*>(hsrc + (((r >> 1) ^ swh) << 4));
+        hr[0][0] = hv.x; hi[0][0] = hv.y; hr[1][0] = hv.z; hi[1][0] = hv.w;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int j = 0; j < NS / 2; ++j) {
+            const int c = (r + a) * (NS / 2) + j;
+            const float4 hv = *reinterpret_cast<const float4*>(hsrc + ((c ^ swh) << 4));
+            hr[a][2 * j] = hv.x; hi[a][2 * j] = hv.y;
+            hr[a][2 * j + 1] = hv.z; hi[a][2 * j + 1] = hv.w;
+          }
+      }
+      gram_row<NS, false>(g, hr[0], hi[0], yv.x, yv.y, 1.0f);
+      gram_row<NS, false>(g, hr[1], hi[1], yv.z, yv.w, 1.0f);
+    }
+    // combine the LPR antenna slices (lanes t, t+T, ...)
+#pragma unroll
+    for (int off = T; off < 64; off <<= 1) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        g.diag[s] += __shfl_xor(g.diag[s], off);
+        g.br[s] += __shfl_xor(g.br[s], off);
+        g.bi[s] += __shfl_xor(g.bi[s], off);
+      }
+#pragma unroll
+      for (int i = 0; i < Gram<NS>::NP; ++i) {
+        g.offr[i] += __shfl_xor(g.offr[i], off);
+        g.offi[i] += __shfl_xor(g.offi[i], off);
+      }
+    }
+    float lam = no_scalar;
+    if (PER_RE_NOISE)
+      lam = *reinterpret_cast<const float*>(smem + buf * BUF + H_TILE + Y_TILE + 4 * t);
+    float xr[NS], xi[NS], ne[NS];
+    lmmse_solve<NS>(g, lam, xr, xi, ne);
+    const long re = tile * T + t;
+    if (re < N) {
+      if (p == 0) {
+        float2* dst = reinterpret_cast<float2*>(x_hat) + re * NS;
+        if (NS % 2 == 0) {
+#pragma unroll
+          for (int s = 0; s < NS; s += 2)
+            *reinterpret_cast<float4*>(dst + s) = make_float4(xr[s], xi[s], xr[s + 1], xi[s + 1]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) dst[s] = make_float2(xr[s], xi[s]);
+        }
+      }
+      if (p == (LPR > 1 ? 1 : 0)) {
+        float* dst = no_eff + re * NS;
+        if (NS == 4) {
+          *reinterpret_cast<float4*>(dst) = make_float4(ne[0], ne[1], ne[2], ne[3]);
+        } else {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) dst[s] = ne[s];
+        }
+      }
+    }
+  };
+
+  long tile = blockIdx.x;
+  int buf = 0;
+  if (tile < n_tiles) fill(0, tile);
+  for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+    const long next = tile + gridDim.x;
+    if (next < n_tiles) {
+      fill(buf ^ 1, next);
+      // everything older than the DMA just issued (this tile's data, earlier stores) is done
+      wait_vmcnt<H_INSTR + Y_INSTR + NO_INSTR>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    compute(buf, tile);
+  }
+}
+
+template <int NR, int NS, int LPR>
+int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+                 float* x_hat, float* no_eff, long N, hipStream_t stream) {
+  constexpr int T = 64 / LPR;
+  const long n_tiles = (N + T - 1) / T;
+  int dev = 0, cus = 256;
+  CET_HIP(hipGetDevice(&dev));
+  CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  long grid = (long)cus * 8;
+  if (grid > n_tiles) grid = n_tiles;
+  if (no_mode == CET_NO_SCALAR) {
+    hipLaunchKernelGGL((lmmse_tiled<NR, NS, LPR, false>), dim3((unsigned)grid), dim3(64), 0, stream,
+                       y, H, no_scalar, no_dev, x_hat, no_eff, N, n_tiles);
+  } else {
+    hipLaunchKernelGGL((lmmse_tiled<NR, NS, LPR, true>), dim3((unsigned)grid), dim3(64), 0, stream,
+                       y, H, no_scalar, no_dev, x_hat, no_eff, N, n_tiles);
+  }
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+
+template <int NR, int NS>
+int launch_direct(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+                  float* x_hat, float* no_eff, long N, hipStream_t stream) {
+  const dim3 block(256), grid((unsigned)((N + 255) / 256));
+  switch (no_mode) {
+    case CET_NO_SCALAR:
+      hipLaunchKernelGGL((lmmse_direct<NR, NS, CET_NO_SCALAR>), grid, block, 0, stream, y, H,
+                         no_scalar, no_dev, x_hat, no_eff, N);
+      break;
+    case CET_NO_PER_RE:
+      hipLaunchKernelGGL((lmmse_direct<NR, NS, CET_NO_PER_RE>), grid, block, 0, stream, y, H,
+                         no_scalar, no_dev, x_hat, no_eff, N);
+      break;
+    default:
+      hipLaunchKernelGGL((lmmse_direct<NR, NS, CET_NO_PER_RE_RX>), grid, block, 0, stream, y, H,
+                         no_scalar, no_dev, x_hat, no_eff, N);
+  }
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+
+// LPR: lanes per RE in the tiled kernel, chosen so that a tile's H block is 16 KiB.
+template <int NR, int NS>
+constexpr int lanes_per_re() {
+  return (NR * NS * 8 >= 512 && NR >= 4) ? 2 : 1;
+}
+
+template <int NR, int NS>
+int dispatch(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+             float* x_hat, float* no_eff, long N, int variant, hipStream_t stream) {
+  if (variant == 1 || no_mode == CET_NO_PER_RE_RX)
+    return launch_direct<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, stream);
+  return launch_tiled<NR, NS, lanes_per_re<NR, NS>()>(y, H, no_mode, no_scalar, no_dev, x_hat,
+                                                       no_eff, N, stream);
+}
+
+}  // namespace
+
+int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+                 float* x_hat, float* no_eff, long N, int Nr, int Ns, int variant,
+                 hipStream_t stream) {
+#define CET_CASE(NR, NS) \
+  if (Nr == NR && Ns == NS) \
+    return dispatch<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, variant, stream);
+  CET_CASE(16, 4) CET_CASE(16, 2) CET_CASE(16, 1)
+  CET_CASE(8, 4) CET_CASE(8, 2) CET_CASE(8, 1)
+  CET_CASE(4, 4) CET_CASE(4, 2) CET_CASE(4, 1)
+  CET_CASE(2, 2) CET_CASE(2, 1)
+#undef CET_CASE
+  return CET_ERR_UNSUPPORTED;
+}
+
+}  // namespace cet

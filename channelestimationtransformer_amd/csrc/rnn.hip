@@ -1,0 +1,461 @@
+// Recurrent channel predictors (RNN / GRU / LSTM `test_data` rollout) for gfx950.
+// Restates LocalSimulations/models/model.py:298-312, 373-388, 449-465 (rollout) and the Unit
+// forwards at :253-270, :327-344, :403-420 as ONE persistent kernel per call: a workgroup
+// takes 32 sequences and runs every time step of every layer without leaving the chip.
+//
+//   * 4 waves per workgroup; wave w owns hidden units [w*H/4, (w+1)*H/4) of every layer and
+//     computes ALL gates of those units, so the cell update is lane-local: the cell state c
+//     (LSTM) and the wave's own slice of h stay in registers for the whole rollout.
+//   * Gate pre-activations are gates^T[unit][sequence] = W * [x ; h]^T on
+//     v_mfma_f32_32x32x2_f32 (A = weight rows, B = activations, fp32 exact). The full h of a
+//     layer (all waves need it as B operand) lives in LDS, [sequence][H+4] floats, read as
+//     conflict-free ds_read_b128 (4 k-steps per read).
+//   * Weights are re-packed once at create time into the exact order a wave consumes them:
+//     1 KiB per (k-block of 8, unit tile, gate), so the dominant stream (the whole weight set,
+//     once per time step per workgroup, from L2) is perfectly linear 16 B/lane loads, software
+//     double-buffered one k-block (32 MFMAs) ahead.
+//   * The decoder Linear consumes the wave's fresh h straight from the accumulator registers
+//     (k = own units), the four partial sums meet in LDS; the encoder Linear of the next step
+//     consumes that result from registers again. In the closed-loop phase nothing but the
+//     predictions ever goes to HBM.
+#include <new>
+#include <vector>
+
+#include "cet_internal.h"
+
+namespace cet {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BT = 32;       // sequences per workgroup
+constexpr int FP = 32;       // features / encoder width, padded
+constexpr int PSTR = FP + 4; // row stride of the partial-sum / x staging buffers
+
+#define DEV __device__ __forceinline__
+
+DEV f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+DEV float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int KIND> struct Cell;
+template <> struct Cell<CET_RNN_TANH> { static constexpr int G = 1, NACC = 1; };
+template <> struct Cell<CET_RNN_GRU> { static constexpr int G = 3, NACC = 4; };   // r, z, n_x, n_h
+template <> struct Cell<CET_RNN_LSTM> { static constexpr int G = 4, NACC = 4; };  // i, f, g, o
+
+struct RArgs {
+  const float* wstream;  // packed gate weights, [layer][wave][unit tile][x|h][k-block][gate][64][4]
+  const float* bias;     // [layer][2][G*H]   (b_ih, b_hh)
+  const float* enc_w;    // [FP][FP] zero padded (row = encoder output unit)
+  const float* enc_b;    // [FP]
+  const float* dec_w;    // [FP][H] zero padded (row = feature)
+  const float* dec_b;    // [FP]
+  const float* x;        // [B][seq][F]
+  float* out;            // [B][pred][F]
+  int B, seq_len, pred_len, F, IP;  // IP: encoder width padded to 16
+};
+
+// C/D row of register r for lane half hh (v_mfma_f32_32x32x2_f32): (r&3) + 8*(r>>2) + 4*hh.
+// Registers 4q..4q+3 are 4 consecutive rows starting at 8*q + 4*hh.
+
+// One k-block (8 k values = 4 MFMA k-steps) for every gate of one unit tile.
+// PART_H: the block belongs to W_hh (selects the accumulator the GRU n gate feeds).
+template <int KIND, bool PART_H>
+DEV void kblock(f32x16 (&acc)[Cell<KIND>::NACC], const f32x4 (&wt)[Cell<KIND>::G],
+                const f32x4 bf) {
+  constexpr int G = Cell<KIND>::G;
+#pragma unroll
+  for (int gt = 0; gt < G; ++gt) {
+    const int ai = (KIND == CET_RNN_GRU && gt == 2 && PART_H) ? 3 : gt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[ai] = mfma32(wt[gt][i], bf[i], acc[ai]);
+  }
+}
+
+template <int N>
+DEV void load_tiles(f32x4 (&dst)[N], const float* src) {
+#pragma unroll
+  for (int t = 0; t < N; ++t) dst[t] = ld4(src + t * 256);
+}
+
+// acc += W_part * act^T over nkb k-blocks (nkb a multiple of 2). `ws`: this lane's position in
+// the packed weight stream; `act`: this lane's activation row (+4*hh) in LDS. Weight tiles are
+// kept two k-blocks ahead of the MFMAs that consume them (three register sets in rotation
+// would need runtime indexing; two sets with the reload issued right after the last use of a
+// set give the same distance at half the registers).
+template <int KIND, bool PART_H>
+DEV void run_part(f32x16 (&acc)[Cell<KIND>::NACC], const float* ws, const float* act, int nkb) {
+  constexpr int G = Cell<KIND>::G;
+  f32x4 w0[G], w1[G];
+  load_tiles<G>(w0, ws);
+  load_tiles<G>(w1, ws + G * 256);
+  for (int kb = 0; kb < nkb; kb += 2) {
+    const f32x4 b0 = ld4(act + 8 * kb), b1 = ld4(act + 8 * kb + 8);
+    kblock<KIND, PART_H>(acc, w0, b0);
+    if (kb + 2 < nkb) load_tiles<G>(w0, ws + (size_t)(kb + 2) * G * 256);
+    kblock<KIND, PART_H>(acc, w1, b1);
+    if (kb + 3 < nkb) load_tiles<G>(w1, ws + (size_t)(kb + 3) * G * 256);
+  }
+}
+
+template <int KIND, int UT, int NL>
+__global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
+  constexpr int H = 128 * UT;
+  constexpr int G = Cell<KIND>::G, NACC = Cell<KIND>::NACC;
+  constexpr int HS = H + 4;        // LDS row stride of an h buffer
+  constexpr int TILE = 256;        // floats per packed weight tile (64 lanes x 4)
+  constexpr bool LSTM = KIND == CET_RNN_LSTM;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xbuf = smem;                       // [BT][PSTR]  encoder output (layer-0 input)
+  float* part = xbuf + BT * PSTR;           // [4][BT][PSTR] decoder partial sums
+  float* hbuf = part + 4 * BT * PSTR;       // [NL][BT][HS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;   // sequence inside the tile (B operand row / C column)
+  const int hh = lane >> 5;  // k half / C row block
+  const int b0 = blockIdx.x * BT;
+  const int bj = (b0 + j < a.B) ? b0 + j : a.B - 1;  // tail tile: replay the last sequence
+
+  for (int i = tid; i < (BT * PSTR * 5 + NL * BT * HS) / 4; i += 256)
+    st4(smem + 4 * i, f32x4{0, 0, 0, 0});
+
+  f32x16 cst[LSTM ? NL : 1][LSTM ? UT : 1];  // LSTM cell state of this wave's units
+#pragma unroll
+  for (int l = 0; l < (LSTM ? NL : 1); ++l)
+#pragma unroll
+    for (int u = 0; u < (LSTM ? UT : 1); ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cst[l][u][r] = 0.f;
+
+  f32x4 xin[4];  // this step's input features, T layout: register q <-> features 8q+4hh..+3
+#pragma unroll
+  for (int q = 0; q < 4; ++q) xin[q] = f32x4{0, 0, 0, 0};
+  auto load_x = [&](int idx, f32x4 (&dst)[4]) {
+    const float* row = a.x + ((size_t)bj * a.seq_len + idx) * a.F;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (8 * q + 4 * hh < a.F) dst[q] = ld4(row + 8 * q + 4 * hh);
+  };
+  load_x(0, xin);
+  __syncthreads();
+
+  const int n_steps = a.seq_len + a.pred_len - 1;
+  for (int idx = 0; idx < n_steps; ++idx) {
+    // The weights do not change between steps, which invites the compiler to hoist hundreds of
+    // loop-invariant loads (all biases, decoder rows) out of the time loop and pin them in
+    // registers. Making the base pointers opaque per iteration keeps them where they are used.
+    const float *wstream = a.wstream, *bias_all = a.bias, *enc_w = a.enc_w, *enc_b = a.enc_b,
+                *dec_w = a.dec_w, *dec_b = a.dec_b;
+    asm volatile("" : "+s"(wstream), "+s"(bias_all), "+s"(enc_w), "+s"(enc_b), "+s"(dec_w),
+                 "+s"(dec_b));
+    // ---- encoder Linear: xe^T = We * x^T + be, from registers; wave 0 publishes it ----
+    f32x4 xnext[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xnext[q] = xin[q];
+    if (idx + 1 < a.seq_len) load_x(idx + 1, xnext);  // prefetch the next teacher-forced input
+    if (wave == 0) {
+      f32x16 e;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = ld4(enc_b + 8 * q + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[4 * q + i] = bv[i];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 wv = ld4(enc_w + j * FP + 8 * q + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e = mfma32(wv[i], xin[q][i], e);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        st4(xbuf + j * PSTR + 8 * q + 4 * hh,
+            f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]});
+    }
+    __syncthreads();
+
+    const bool decode = idx >= a.seq_len - 1;  // decoder output needed from here on
+    f32x16 dec_acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dec_acc[r] = 0.f;
+
+    // ---- the layers ---------------------------------------------------------------------
+    const float* wp = wstream;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const float* in_buf = l == 0 ? xbuf : hbuf + (l - 1) * BT * HS;
+      const int in_stride = l == 0 ? PSTR : HS;
+      const int nkb_x = l == 0 ? a.IP / 8 : H / 8;
+      float* hl = hbuf + l * BT * HS;
+      const size_t tile_floats = (size_t)(nkb_x + H / 8) * G * TILE;  // one (wave, unit tile)
+      const float* ws = wp + (size_t)wave * UT * tile_floats + lane * 4;
+      wp += (size_t)4 * UT * tile_floats;
+      const float* bi = bias_all + (size_t)l * 2 * G * H;
+      const float* bh = bi + G * H;
+
+      f32x16 hnew[UT];
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int u0 = wave * (32 * UT) + 32 * u;  // first unit of this tile
+        f32x16 acc[NACC];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int off = u0 + 8 * q + 4 * hh;
+#pragma unroll
+          for (int gt = 0; gt < G; ++gt) {
+            const f32x4 v1 = ld4(bi + gt * H + off), v2 = ld4(bh + gt * H + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (KIND == CET_RNN_GRU && gt == 2) {
+                acc[2][4 * q + i] = v1[i];  // n gate keeps W_in x + b_in ...
+                acc[3][4 * q + i] = v2[i];  // ... apart from W_hn h + b_hn
+              } else {
+                acc[gt][4 * q + i] = v1[i] + v2[i];
+              }
+            }
+          }
+        }
+        run_part<KIND, false>(acc, ws, in_buf + j * in_stride + 4 * hh, nkb_x);
+        ws += (size_t)nkb_x * G * TILE;
+        run_part<KIND, true>(acc, ws, hl + j * HS + 4 * hh, H / 8);
+        ws += (size_t)(H / 8) * G * TILE;
+
+        // cell update, lane-local
+        f32x16 hprev;
+        if (KIND == CET_RNN_GRU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = ld4(hl + j * HS + u0 + 8 * q + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hprev[4 * q + i] = v[i];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float hv;
+          if (KIND == CET_RNN_TANH) {
+            hv = tanhf(acc[0][r]);
+          } else if (KIND == CET_RNN_GRU) {
+            const float rg = sigmoidf_(acc[0][r]);
+            const float zg = sigmoidf_(acc[1][r]);
+            const float ng = tanhf(acc[2][r] + rg * acc[3][r]);
+            hv = (1.0f - zg) * ng + zg * hprev[r];
+          } else {
+            const float ig = sigmoidf_(acc[0][r]);
+            const float fg = sigmoidf_(acc[1][r]);
+            const float gg = tanhf(acc[2][r]);
+            const float og = sigmoidf_(acc[3][r]);
+            const float cv = fg * cst[LSTM ? l : 0][LSTM ? u : 0][r] + ig * gg;
+            cst[LSTM ? l : 0][LSTM ? u : 0][r] = cv;
+            hv = og * tanhf(cv);
+          }
+          hnew[u][r] = hv;
+        }
+        // decoder Linear partial over this tile's units, straight from the registers
+        if (l == NL - 1 && decode) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = ld4(dec_w + (size_t)j * H + u0 + 8 * q + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dec_acc = mfma32(wv[i], hnew[u][4 * q + i], dec_acc);
+          }
+        }
+      }
+      __syncthreads();  // every wave has finished reading the old h of this layer
+#pragma unroll
+      for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          st4(hl + j * HS + wave * (32 * UT) + 32 * u + 8 * q + 4 * hh,
+              f32x4{hnew[u][4 * q], hnew[u][4 * q + 1], hnew[u][4 * q + 2], hnew[u][4 * q + 3]});
+      if (l == NL - 1 && decode) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          st4(part + (wave * BT + j) * PSTR + 8 * q + 4 * hh,
+              f32x4{dec_acc[4 * q], dec_acc[4 * q + 1], dec_acc[4 * q + 2], dec_acc[4 * q + 3]});
+      }
+      __syncthreads();
+    }
+
+    // ---- decoder output = bias + the four waves' partial sums (fixed order) ----------------
+    if (decode) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 s = ld4(dec_b + 8 * q + 4 * hh);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += ld4(part + (w * BT + j) * PSTR + 8 * q + 4 * hh);
+        xnext[q] = s;  // next step's input, already in registers in every wave
+      }
+      if (wave == 1 && b0 + j < a.B) {
+        float* dst = a.out + ((size_t)(b0 + j) * a.pred_len + (idx - (a.seq_len - 1))) * a.F;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (8 * q + 4 * hh < a.F) st4(dst + 8 * q + 4 * hh, xnext[q]);
+      }
+      // `part` is written again only after the barriers of the next step
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xin[q] = xnext[q];
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// Host side
+
+struct RnnModel {
+  int kind, F, I, H, layers, IP;
+  float* dev = nullptr;  // one allocation; the pointers below point into it
+  const float *wstream, *bias, *enc_w, *enc_b, *dec_w, *dec_b;
+};
+
+static int gates_of(int kind) { return kind == CET_RNN_TANH ? 1 : (kind == CET_RNN_GRU ? 3 : 4); }
+
+static bool rnn_supported(int kind, int F, int I, int H, int layers) {
+  if (kind < CET_RNN_TANH || kind > CET_RNN_LSTM) return false;
+  if (H != 128 && H != 256) return false;
+  if (layers < 1 || layers > 3) return false;
+  if (F < 4 || F > FP || F % 4) return false;
+  if (I < 1 || I > FP) return false;
+  return true;
+}
+
+size_t rnn_blob_size(int kind, int F, int I, int H, int layers) {
+  if (kind < CET_RNN_TANH || kind > CET_RNN_LSTM || F < 1 || I < 1 || H < 1 || layers < 1) return 0;
+  const size_t G = gates_of(kind);
+  size_t n = (size_t)I * F + I;
+  for (int l = 0; l < layers; ++l) {
+    const size_t in = l == 0 ? I : H;
+    n += G * H * in + G * H * H + 2 * G * H;
+  }
+  return n + (size_t)F * H + F;
+}
+
+int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t n, RnnModel** out) {
+  if (!rnn_supported(kind, F, I, H, layers)) return CET_ERR_UNSUPPORTED;
+  if (n != rnn_blob_size(kind, F, I, H, layers)) return CET_ERR_BLOB_SIZE;
+  const int G = gates_of(kind);
+  const int IP = (I + 15) / 16 * 16;
+  const int UT = H / 128;
+
+  const float* p = w;
+  const float* enc_w = p; p += (size_t)I * F;
+  const float* enc_b = p; p += I;
+  std::vector<float> stream, bias;
+  for (int l = 0; l < layers; ++l) {
+    const int in = l == 0 ? I : H;          // true input width
+    const int in_p = l == 0 ? IP : H;       // padded (zero weights beyond `in`)
+    const float* w_ih = p; p += (size_t)G * H * in;
+    const float* w_hh = p; p += (size_t)G * H * H;
+    const float* b_ih = p; p += (size_t)G * H;
+    const float* b_hh = p; p += (size_t)G * H;
+    bias.insert(bias.end(), b_ih, b_ih + (size_t)G * H);
+    bias.insert(bias.end(), b_hh, b_hh + (size_t)G * H);
+    for (int wave = 0; wave < 4; ++wave)
+      for (int u = 0; u < UT; ++u)
+        for (int part = 0; part < 2; ++part) {
+          const float* W = part == 0 ? w_ih : w_hh;
+          const int K = part == 0 ? in : H, KP = part == 0 ? in_p : H;
+          for (int kb = 0; kb < KP / 8; ++kb)
+            for (int g = 0; g < G; ++g)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                  const int unit = wave * 32 * UT + 32 * u + (lane & 31);
+                  const int k = 8 * kb + 4 * (lane >> 5) + i;
+                  stream.push_back(k < K ? W[((size_t)g * H + unit) * K + k] : 0.f);
+                }
+        }
+  }
+  const float* dec_w = p; p += (size_t)F * H;
+  const float* dec_b = p; p += F;
+  if ((size_t)(p - w) != n) return CET_ERR_BLOB_SIZE;
+
+  std::vector<float> ew((size_t)FP * FP, 0.f), eb(FP, 0.f), dw((size_t)FP * H, 0.f), db(FP, 0.f);
+  for (int r = 0; r < I; ++r) {
+    for (int c = 0; c < F; ++c) ew[(size_t)r * FP + c] = enc_w[(size_t)r * F + c];
+    eb[r] = enc_b[r];
+  }
+  for (int r = 0; r < F; ++r) {
+    for (int c = 0; c < H; ++c) dw[(size_t)r * H + c] = dec_w[(size_t)r * H + c];
+    db[r] = dec_b[r];
+  }
+
+  RnnModel* m = new (std::nothrow) RnnModel;
+  if (!m) return CET_ERR_ALLOC;
+  m->kind = kind; m->F = F; m->I = I; m->H = H; m->layers = layers; m->IP = IP;
+  std::vector<float> all;
+  auto place = [&](const std::vector<float>& v) {
+    const size_t off = all.size();
+    all.insert(all.end(), v.begin(), v.end());
+    while (all.size() % 64) all.push_back(0.f);  // keep every block 256-byte aligned
+    return off;
+  };
+  const size_t o_stream = place(stream), o_bias = place(bias), o_ew = place(ew), o_eb = place(eb),
+               o_dw = place(dw), o_db = place(db);
+  hipError_t e = hipMalloc(&m->dev, all.size() * sizeof(float));
+  if (e == hipSuccess)
+    e = hipMemcpy(m->dev, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (m->dev) (void)hipFree(m->dev);
+    delete m;
+    return hip_fail(e);
+  }
+  m->wstream = m->dev + o_stream; m->bias = m->dev + o_bias; m->enc_w = m->dev + o_ew;
+  m->enc_b = m->dev + o_eb; m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
+  *out = m;
+  return CET_OK;
+}
+
+void rnn_destroy(RnnModel* m) {
+  if (!m) return;
+  if (m->dev) (void)hipFree(m->dev);
+  delete m;
+}
+
+template <int KIND, int UT, int NL>
+static int launch(const RArgs& a, hipStream_t stream) {
+  constexpr int H = 128 * UT;
+  const size_t lds = sizeof(float) * (size_t)(BT * PSTR * 5 + NL * BT * (H + 4));
+  CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_rollout_kernel<KIND, UT, NL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned grid = (unsigned)((a.B + BT - 1) / BT);
+  hipLaunchKernelGGL((rnn_rollout_kernel<KIND, UT, NL>), dim3(grid), dim3(256), lds, stream, a);
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+
+template <int KIND>
+static int launch_kind(const RnnModel* m, const RArgs& a, hipStream_t s) {
+  const int ut = m->H / 128;
+  if (ut == 1 && m->layers == 1) return launch<KIND, 1, 1>(a, s);
+  if (ut == 1 && m->layers == 2) return launch<KIND, 1, 2>(a, s);
+  if (ut == 1 && m->layers == 3) return launch<KIND, 1, 3>(a, s);
+  if (ut == 2 && m->layers == 1) return launch<KIND, 2, 1>(a, s);
+  if (ut == 2 && m->layers == 2) return launch<KIND, 2, 2>(a, s);
+  if (ut == 2 && m->layers == 3) return launch<KIND, 2, 3>(a, s);
+  return CET_ERR_UNSUPPORTED;
+}
+
+int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                hipStream_t stream) {
+  RArgs a{};
+  a.wstream = m->wstream; a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b;
+  a.dec_w = m->dec_w; a.dec_b = m->dec_b; a.x = x; a.out = out;
+  a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F; a.IP = m->IP;
+  switch (m->kind) {
+    case CET_RNN_TANH: return launch_kind<CET_RNN_TANH>(m, a, stream);
+    case CET_RNN_GRU: return launch_kind<CET_RNN_GRU>(m, a, stream);
+    default: return launch_kind<CET_RNN_LSTM>(m, a, stream);
+  }
+}
+
+}  // namespace cet

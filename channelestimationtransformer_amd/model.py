@@ -1,0 +1,296 @@
+"""Host-side mirrors of the reference's predictor classes.
+
+Same constructor signatures, same `forward` / `test_data` call signatures and the same
+`state_dict` key names as LocalSimulations/models/model.py, so the reference's checkpoints
+load with `load_state_dict` unchanged and its driver scripts run as written. The modules
+only *hold* parameters: all arithmetic happens in the HIP kernels of csrc/ (reached through
+`torch.ops.cet.*`). There is no CPU implementation behind them; calling one with CPU tensors
+raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _cabi, blobs
+from . import ops  # noqa: F401  (registers torch.ops.cet.*)
+
+
+class _Node(nn.Module):
+    """Bare container; children are attached under the reference's attribute names."""
+
+
+class _DeviceWeights(nn.Module):
+    """Keeps one library handle (packed weights on the GPU) per device.
+
+    Packing walks the whole state_dict, so it is not repeated per call: the handle is rebuilt
+    only after `load_state_dict`, after `.to()/.cuda()/.float()` style conversions, or when
+    `refresh_weights()` is called (needed after modifying parameters in place)."""
+
+    def __init__(self):
+        super().__init__()
+        self._weights_version = 0
+        self._handles = {}  # device index -> (version, handle, extra)
+
+    def refresh_weights(self):
+        self._weights_version += 1
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        self._weights_version += 1
+        return super().load_state_dict(blobs.normalize_state_dict(state_dict), *args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._weights_version += 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def _create(self, device_index):  # -> (handle, extra)
+        raise NotImplementedError
+
+    def _handle_for(self, device):
+        if self.training:
+            raise RuntimeError("the HIP path implements the eval-mode forward only: call .eval() "
+                               "first (the reference's drivers do, Predict.py:94)")
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        cached = self._handles.get(key)
+        if cached is not None and cached[0] == self._weights_version:
+            return cached[1], cached[2]
+        if cached is not None:
+            _cabi.lib().cet_destroy(cached[1])
+            del self._handles[key]
+        with torch.cuda.device(key):
+            handle, extra = self._create(key)
+        self._handles[key] = (self._weights_version, handle, extra)
+        return handle, extra
+
+    def __del__(self):
+        try:
+            for _, h, _x in self._handles.values():
+                _cabi.lib().cet_destroy(h)
+        except Exception:
+            pass
+
+
+def _attention_holder(d_model):
+    n = _Node()
+    for name in ("query_projection", "key_projection", "value_projection", "out_projection"):
+        setattr(n, name, nn.Linear(d_model, d_model))
+    return n
+
+
+def _ffn_into(node, d_model, d_ff, norms):
+    node.conv1 = nn.Conv1d(d_model, d_ff, kernel_size=1)
+    node.conv2 = nn.Conv1d(d_ff, d_model, kernel_size=1)
+    for name in norms:
+        setattr(node, name, nn.LayerNorm(d_model))
+
+
+def _embedding_holder(c_in, d_model, max_len=5000):
+    """`value_embedding.tokenConv` + the fixed sinusoid table `position_embedding.pe`
+    (LocalSimulations/models/embed.py:7-38); the table is a registered buffer there, so it is
+    part of the state_dict here too."""
+    emb = _Node()
+    emb.value_embedding = _Node()
+    conv = nn.Conv1d(c_in, d_model, kernel_size=3, padding=1, padding_mode="circular")
+    nn.init.kaiming_normal_(conv.weight, mode="fan_in", nonlinearity="leaky_relu")
+    emb.value_embedding.tokenConv = conv
+    pos = torch.arange(0, max_len).float().unsqueeze(1)
+    div = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()
+    pe = torch.zeros(max_len, d_model)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    emb.position_embedding = _Node()
+    emb.position_embedding.register_buffer("pe", pe.unsqueeze(0))
+    return emb
+
+
+def _encoder_holder(n_layers, d_model, d_ff, distil):
+    enc = _Node()
+    layers = []
+    for _ in range(n_layers):
+        lay = _Node()
+        lay.attention = _attention_holder(d_model)
+        _ffn_into(lay, d_model, d_ff, ("norm1", "norm2"))
+        layers.append(lay)
+    enc.attn_layers = nn.ModuleList(layers)
+    if distil:
+        convs = []
+        for _ in range(n_layers - 1):
+            c = _Node()
+            c.downConv = nn.Conv1d(d_model, d_model, kernel_size=3, padding=2, padding_mode="circular")
+            c.norm = nn.BatchNorm1d(d_model)
+            convs.append(c)
+        enc.conv_layers = nn.ModuleList(convs)
+    enc.norm = nn.LayerNorm(d_model)
+    return enc
+
+
+class _InformerBase(_DeviceWeights):
+    _stack = True
+
+    def __init__(self, enc_in, dec_in, c_out, seq_len, label_len, out_len, factor=5, d_model=512,
+                 n_heads=8, e_layers=3, d_layers=2, d_ff=512, dropout=0.0, attn="prob",
+                 embed="fixed", activation="gelu", output_attention=False, distil=True,
+                 device=None):
+        super().__init__()
+        if attn != "full":
+            raise NotImplementedError(
+                "only attn='full' is implemented (every driver of the reference sets it; "
+                "ProbSparse attention samples keys at random)")
+        self.pred_len = out_len
+        self.attn = attn
+        self.output_attention = output_attention
+        # `device` is accepted and ignored, as in the reference (model.py:165).
+        self._cfg = blobs.make_informer_cfg(enc_in, dec_in, c_out, seq_len, label_len, out_len,
+                                            d_model, n_heads, e_layers, d_layers, d_ff,
+                                            self._stack, distil, activation)
+        self.enc_embedding = _embedding_holder(enc_in, d_model)
+        self.dec_embedding = _embedding_holder(dec_in, d_model)
+        depths = blobs.encoder_depths(e_layers, self._stack)
+        if self._stack:
+            self.encoder = _Node()
+            self.encoder.encoders = nn.ModuleList(
+                [_encoder_holder(el, d_model, d_ff, distil) for el in depths])
+        else:
+            self.encoder = _encoder_holder(e_layers, d_model, d_ff, distil)
+        self.decoder = _Node()
+        dec_layers = []
+        for _ in range(d_layers):
+            lay = _Node()
+            lay.self_attention = _attention_holder(d_model)
+            lay.cross_attention = _attention_holder(d_model)
+            _ffn_into(lay, d_model, d_ff, ("norm1", "norm2", "norm3"))
+            dec_layers.append(lay)
+        self.decoder.layers = nn.ModuleList(dec_layers)
+        self.decoder.norm = nn.LayerNorm(d_model)
+        self.projection = nn.Linear(d_model, c_out, bias=True)
+
+    def _create(self, device_index):
+        blob = np.ascontiguousarray(blobs.pack_informer(self.state_dict(), self._cfg))
+        L = _cabi.lib()
+        h = ctypes.c_void_p()
+        rc = L.cet_informer_create(ctypes.byref(self._cfg), blob.ctypes.data_as(ctypes.c_void_p),
+                                   blob.size, ctypes.byref(h))
+        _cabi.check(rc, "cet_informer_create")
+        return h, L.cet_informer_attn_size(h, 1)
+
+    # -- the reference's call signature ---------------------------------------------------
+    def forward(self, x_enc, x_dec, enc_self_mask=None, dec_self_mask=None, dec_enc_mask=None):
+        """`[B, seq_len, enc_in]`, `[B, label_len+out_len, dec_in]` -> `[B, out_len, c_out]`,
+        or `(pred, attns)` when `output_attention` (LocalSimulations/models/model.py:220-234)."""
+        if enc_self_mask is not None or dec_self_mask is not None or dec_enc_mask is not None:
+            raise NotImplementedError("explicit attention masks are not supported (the "
+                                      "reference's callers always pass None)")
+        c = self._cfg
+        if x_enc.dim() != 3 or tuple(x_enc.shape[1:]) != (c.seq_len, c.enc_in):
+            raise RuntimeError(f"x_enc must be [B, {c.seq_len}, {c.enc_in}], got {tuple(x_enc.shape)}")
+        if x_dec.dim() != 3 or tuple(x_dec.shape) != (x_enc.shape[0], c.label_len + c.pred_len, c.dec_in):
+            raise RuntimeError(f"x_dec must be [{x_enc.shape[0]}, {c.label_len + c.pred_len}, "
+                               f"{c.dec_in}], got {tuple(x_dec.shape)}")
+        if not x_enc.is_cuda:
+            raise RuntimeError("x_enc is on the CPU: this implementation runs on ROCm GPUs only")
+        handle, per_sample = self._handle_for(x_enc.device)
+        want = per_sample if self.output_attention else 0
+        pred, attn = torch.ops.cet.informer_forward(x_enc, x_dec, handle.value, c.pred_len,
+                                                    c.c_out, want)
+        if not self.output_attention:
+            return pred
+        return pred, self._split_attention(attn, x_enc.shape[0])
+
+    def _split_attention(self, flat, B):
+        """Flat map buffer -> the reference's nesting: one list per encoder of the stack
+        (a flat list for Informer), one `[B, n_heads, L, L]` tensor per attention layer."""
+        c = self._cfg
+        depths = blobs.encoder_depths(c.e_layers, c.stack)
+        out, off = [], 0
+        inp_len = cur = c.seq_len
+        for el in depths:
+            L = min(inp_len, cur)
+            maps = []
+            for l in range(el):
+                n = B * c.n_heads * L * L
+                maps.append(flat[off:off + n].view(B, c.n_heads, L, L))
+                off += n
+                if c.distil and l < el - 1:
+                    L = (L + 1) // 2 + 1
+            out.append(maps)
+            cur, inp_len = L, inp_len // 2
+        return out if c.stack else out[0]
+
+
+class InformerStack(_InformerBase):
+    """LocalSimulations/models/model.py:160-234."""
+    _stack = True
+
+
+class InformerStack_e2e(_InformerBase):
+    """LocalSimulations/models/model.py:84-158 (same wiring as InformerStack)."""
+    _stack = True
+
+
+class Informer(_InformerBase):
+    """LocalSimulations/models/model.py:11-81 (single encoder)."""
+    _stack = False
+
+
+# ---------------------------------------------------------------------------------------
+
+
+class _RecurrentBase(_DeviceWeights):
+    _cell = None  # "rnn" | "gru" | "lstm"
+
+    def __init__(self, features, input_size, hidden_size, num_layers=2):
+        super().__init__()
+        self.num_layers = num_layers
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.features = features
+        unit = _Node()
+        unit.encoder = nn.Sequential(nn.Linear(features, input_size))
+        cell_cls = {"rnn": nn.RNN, "gru": nn.GRU, "lstm": nn.LSTM}[self._cell]
+        setattr(unit, self._cell, cell_cls(input_size, hidden_size, num_layers))
+        unit.decoder = nn.Sequential(nn.Linear(hidden_size, features))
+        self.model = unit
+
+    def _create(self, device_index):
+        kind = blobs.RNN_KINDS[self._cell]
+        blob = np.ascontiguousarray(blobs.pack_rnn(self.state_dict(), kind, self.features,
+                                                   self.input_size, self.hidden_size,
+                                                   self.num_layers))
+        h = ctypes.c_void_p()
+        rc = _cabi.lib().cet_rnn_create(kind, self.features, self.input_size, self.hidden_size,
+                                        self.num_layers, blob.ctypes.data_as(ctypes.c_void_p),
+                                        blob.size, ctypes.byref(h))
+        _cabi.check(rc, "cet_rnn_create")
+        return h, None
+
+    def test_data(self, x, pred_len, device=None):
+        """`[B, seq_len, features]` -> `[B, pred_len, features]`: seq_len teacher-forced steps,
+        then closed-loop prediction (LocalSimulations/models/model.py:298-312, 373-388,
+        449-465). `device` is accepted for signature compatibility; the rollout runs where
+        `x` lives."""
+        if x.dim() != 3 or x.shape[2] != self.features:
+            raise RuntimeError(f"x must be [B, seq_len, {self.features}], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("x is on the CPU: this implementation runs on ROCm GPUs only")
+        return torch.ops.cet.rnn_rollout(x, self._handle_for(x.device)[0].value, int(pred_len))
+
+    def train_data(self, x, device=None):
+        raise NotImplementedError("training (teacher-forced `train_data`) is outside the "
+                                  "inference path this package implements")
+
+
+class RNN(_RecurrentBase):
+    """LocalSimulations/models/model.py:272-312."""
+    _cell = "rnn"
+
+
+class GRU(_RecurrentBase):
+    """LocalSimulations/models/model.py:346-388."""
+    _cell = "gru"
+
+
+class LSTM(_RecurrentBase):
+    """LocalSimulations/models/model.py:422-465."""
+    _cell = "lstm"

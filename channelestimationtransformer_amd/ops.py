@@ -1,0 +1,96 @@
+"""PyTorch custom ops (`torch.ops.cet.*`) in front of the C ABI.
+
+Each op checks device / dtype / contiguity, allocates the outputs with torch (the library
+never allocates results) and enqueues the HIP kernel on torch's current stream through the
+ctypes binding. Handles are created and owned by the host-side model objects.
+"""
+import ctypes
+
+import torch
+
+from . import _cabi
+
+_NO_ARG = torch.empty(0)
+
+
+def _dev_check(*tensors):
+    dev = tensors[0].device
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "channelestimationtransformer_amd computes on the GPU only: got a tensor on "
+                f"{t.device}; move inputs to a ROCm device (there is no CPU path)")
+        if t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {t.device} vs {dev}")
+    return dev
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+
+
+@torch.library.custom_op("cet::informer_forward", mutates_args=())
+def informer_forward(x_enc: torch.Tensor, x_dec: torch.Tensor, handle: int, pred_len: int,
+                     c_out: int, attn_floats_per_sample: int) -> tuple[torch.Tensor, torch.Tensor]:
+    dev = _dev_check(x_enc, x_dec)
+    x_enc = x_enc.contiguous().float()
+    x_dec = x_dec.contiguous().float()
+    B = x_enc.shape[0]
+    out = torch.empty((B, pred_len, c_out), dtype=torch.float32, device=dev)
+    attn = torch.empty((B * attn_floats_per_sample,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().cet_informer_forward(
+            ctypes.c_void_p(handle), _ptr(x_enc), _ptr(x_dec), _ptr(out), _ptr(attn), B,
+            _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_informer_forward")
+    return out, attn
+
+
+@informer_forward.register_fake
+def _(x_enc, x_dec, handle, pred_len, c_out, attn_floats_per_sample):
+    B = x_enc.shape[0]
+    return (x_enc.new_empty((B, pred_len, c_out)), x_enc.new_empty((B * attn_floats_per_sample,)))
+
+
+@torch.library.custom_op("cet::rnn_rollout", mutates_args=())
+def rnn_rollout(x: torch.Tensor, handle: int, pred_len: int) -> torch.Tensor:
+    dev = _dev_check(x)
+    x = x.contiguous().float()
+    B, seq_len, F = x.shape
+    out = torch.empty((B, pred_len, F), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().cet_rnn_rollout(ctypes.c_void_p(handle), _ptr(x), _ptr(out), B, seq_len,
+                                         pred_len, _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_rnn_rollout")
+    return out
+
+
+@rnn_rollout.register_fake
+def _(x, handle, pred_len):
+    return x.new_empty((x.shape[0], pred_len, x.shape[2]))
+
+
+@torch.library.custom_op("cet::lmmse", mutates_args=())
+def lmmse(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: float,
+          no_mode: int, direct: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    """y [N,Nr,2], H [N,Nr,Ns,2] float32 (interleaved complex) -> x_hat [N,Ns,2], no_eff [N,Ns]."""
+    dev = _dev_check(y, H)
+    y = y.contiguous()
+    H = H.contiguous()
+    N, Nr, Ns = H.shape[0], H.shape[1], H.shape[2]
+    x_hat = torch.empty((N, Ns, 2), dtype=torch.float32, device=dev)
+    no_eff = torch.empty((N, Ns), dtype=torch.float32, device=dev)
+    no_dev = no.contiguous() if no_mode != 0 else None
+    L = _cabi.lib()
+    fn = L.cet_lmmse_direct if direct else L.cet_lmmse
+    with torch.cuda.device(dev):
+        rc = fn(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar), _ptr(no_dev), _ptr(x_hat),
+                _ptr(no_eff), ctypes.c_long(N), Nr, Ns, _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_lmmse")
+    return x_hat, no_eff
+
+
+@lmmse.register_fake
+def _(y, H, no, no_scalar, no_mode, direct):
+    N, Ns = H.shape[0], H.shape[2]
+    return y.new_empty((N, Ns, 2)), y.new_empty((N, Ns))

@@ -148,6 +148,13 @@ enum {
 int cet_lmmse(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
               float* x_hat, float* no_eff, long N, int Nr, int Ns, void* stream);
 
+/* Same contract as cet_lmmse, served by the plain one-resource-element-per-thread kernel
+ * (no LDS staging). Kept as an independent implementation the tiled kernel is checked
+ * against on the GPU; it is also what cet_lmmse uses for CET_NO_PER_RE_RX. */
+int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scalar,
+                     const float* no_dev, float* x_hat, float* no_eff, long N, int Nr, int Ns,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

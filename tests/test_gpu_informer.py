@@ -1,0 +1,157 @@
+"""Parity of the HIP Transformer predictor (through the host module and the C ABI) with the
+golden vectors from the reference and with the CPU checker."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import (DEFAULT_ARGS, INFORMER_VARIANTS, cfg_from_args, dec_input_np, load_batch_np,
+                      load_npz, sub_dict)
+import channelestimationtransformer_amd as cet
+from channelestimationtransformer_amd import _cabi, blobs
+
+pytestmark = pytest.mark.gpu
+
+# fp32 throughout; the reference itself reproduces its stored outputs to ~1.2e-6.
+TOL_PRED = 2e-5   # max-abs on outputs of magnitude <= ~2.5
+TOL_STAGE = 5e-5  # max-abs on internal activations (LayerNorm outputs, magnitude <= ~10)
+TOL_ATTN = 5e-6   # attention probabilities
+
+
+def to_torch_sd(d):
+    sd = {}
+    for k, v in d.items():
+        t = torch.from_numpy(np.array(v))
+        if k.endswith("position_embedding.pe"):
+            full = torch.zeros(1, 5000, t.shape[-1])
+            full[:, :t.shape[1]] = t
+            t = full
+        sd[k] = t
+    return sd
+
+
+def build(cls_name, args, sd):
+    m = getattr(cet, cls_name)(*args)
+    m.load_state_dict(to_torch_sd(sd))
+    return m.eval()
+
+
+def run_taps(m, x_enc, x_dec):
+    """Direct C-ABI call of the debug entry point -> (pred, taps list, attn list)."""
+    L = _cabi.lib()
+    dev = torch.device("cuda:0")
+    h, _ = m._handle_for(dev)
+    B = x_enc.shape[0]
+    c = m._cfg
+    xe = torch.from_numpy(x_enc).to(dev)
+    xd = torch.from_numpy(x_dec).to(dev)
+    out = torch.empty(B, c.pred_len, c.c_out, device=dev)
+    taps = torch.full((L.cet_informer_taps_size(h, B),), float("nan"), device=dev)
+    attn = torch.full((L.cet_informer_attn_size(h, B),), float("nan"), device=dev)
+    rc = L.cet_informer_forward_taps(h, xe.data_ptr(), xd.data_ptr(), out.data_ptr(), attn.data_ptr(),
+                                     taps.data_ptr(), B, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), taps.cpu().numpy(), attn.cpu().numpy()
+
+
+def test_stored_pairs_of_the_reference():
+    """CR_data_{30,36,60} -> CR_transformer_{30,36,60} with the shipped checkpoint, following
+    LocalSimulations/Predict.py:99-120 line by line."""
+    cr = load_npz("cr_pairs.npz")
+    m = build("InformerStack", DEFAULT_ARGS, dict(load_npz("informer_ckpt.npz"))).to("cuda")
+    for tag in ("30", "36", "60"):
+        channel = cr[f"data_{tag}"]
+        data = cet.LoadBatch(channel[:, :25, :, :])
+        enc_inp = data.to("cuda")
+        dec_inp = torch.zeros_like(enc_inp[:, -5:, :])
+        dec_inp = torch.cat([enc_inp[:, 25 - 10:25, :], dec_inp], dim=1)
+        outputs = m(enc_inp, dec_inp)[0]
+        outputs = cet.real2complex(np.array(outputs.cpu().detach())).reshape([64, 5, 4, 2])
+        assert np.abs(outputs - cr[f"transformer_{tag}"]).max() < TOL_PRED
+
+
+def test_every_stage_against_reference_activations(oracle):
+    ref = load_npz("informer_ref.npz")
+    m = build("InformerStack", DEFAULT_ARGS, dict(load_npz("informer_ckpt.npz")))
+    pred, taps, attn = run_taps(m, ref["x_enc"], ref["x_dec"])
+    rows = oracle.tap_rows(m._cfg)
+    taps = oracle.split_taps(taps, rows, 8, 64)
+    attn = oracle.split_attn(attn, oracle.attn_lengths(m._cfg), 8, 8)
+    for i, t in enumerate(taps):
+        err = np.abs(t - ref[f"tap_{i}"]).max()
+        assert err < TOL_STAGE, f"stage {i} (rows {rows[i]}): max abs err {err}"
+    for i, a in enumerate(attn):
+        err = np.abs(a - ref[f"attn_{i}"]).max()
+        assert err < TOL_ATTN, f"attention map {i}: {err}"
+    assert np.abs(pred - ref["pred"]).max() < TOL_PRED
+
+
+@pytest.mark.parametrize("name", sorted(INFORMER_VARIANTS))
+def test_other_wirings(name, oracle):
+    v = load_npz("informer_variants.npz")
+    cls, args = INFORMER_VARIANTS[name]
+    m = build(cls, args, sub_dict(v, f"{name}/sd"))
+    pred, taps, attn = run_taps(m, v[f"{name}/x_enc"], v[f"{name}/x_dec"])
+    B = v[f"{name}/x_enc"].shape[0]
+    rows = oracle.tap_rows(m._cfg)
+    for i, t in enumerate(oracle.split_taps(taps, rows, B, 64)):
+        err = np.abs(t - v[f"{name}/tap_{i}"]).max()
+        assert err < TOL_STAGE, f"{name} stage {i}: {err}"
+    assert np.abs(pred - v[f"{name}/pred"]).max() < TOL_PRED
+    for i, a in enumerate(oracle.split_attn(attn, oracle.attn_lengths(m._cfg), B, 8)):
+        if f"{name}/attn_{i}" in v.files:
+            assert np.abs(a - v[f"{name}/attn_{i}"]).max() < TOL_ATTN
+
+
+def test_module_api_and_attention_nesting(oracle):
+    ck = dict(load_npz("informer_ckpt.npz"))
+    m = build("InformerStack", DEFAULT_ARGS, ck).cuda()
+    from channelestimationtransformer_amd import synth
+    noisy, _ = synth.channel_histories(37, seed=5)  # ragged batch (not a multiple of anything)
+    x = cet.LoadBatch(noisy[:, :25]).cuda()
+    xd = cet.decoder_input(x, 10, 5)
+    pred, attns = m(x, xd)
+    assert pred.shape == (37, 5, 16) and len(attns) == 2 and [len(a) for a in attns] == [4, 3]
+    assert [a.shape[-1] for a in attns[0]] == [25, 14, 8, 5] and [a.shape[-1] for a in attns[1]] == [5, 4, 3]
+    cfg = m._cfg
+    want, want_attn, _ = oracle.informer_forward(cfg, blobs.pack_informer(ck, cfg), x.cpu().numpy(),
+                                                 xd.cpu().numpy(), want_attn=True)
+    assert np.abs(pred.cpu().numpy() - want).max() < TOL_PRED
+    flat = [a for grp in attns for a in grp]
+    for a, w in zip(flat, want_attn):
+        assert np.abs(a.cpu().numpy() - w).max() < TOL_ATTN
+        assert torch.allclose(a.sum(-1), torch.ones_like(a.sum(-1)), atol=1e-5)
+    # output_attention=False returns the bare tensor, bit-identical predictions
+    m.output_attention = False
+    p2 = m(x, xd)
+    assert isinstance(p2, torch.Tensor) and torch.equal(p2, pred)
+    # batch of one, and an empty batch
+    assert torch.equal(m(x[:1], xd[:1]), pred[:1])
+    assert m(x[:0], xd[:0]).shape == (0, 5, 16)
+
+
+def test_full_size_batch_properties(oracle):
+    """Batch 4096 (the benchmark size): per-sample independence (any sub-batch gives the
+    same bits) and agreement with the CPU checker on a strided sample of the batch."""
+    from channelestimationtransformer_amd import synth
+    ck = dict(load_npz("informer_ckpt.npz"))
+    m = build("InformerStack", DEFAULT_ARGS, ck).cuda()
+    m.output_attention = False
+    noisy, _ = synth.channel_histories(4096, seed=0)
+    x = cet.LoadBatch(noisy[:, :25]).cuda()
+    xd = cet.decoder_input(x, 10, 5)
+    full = m(x, xd)
+    assert torch.isfinite(full).all()
+    idx = torch.arange(0, 4096, 61, device="cuda")
+    assert torch.equal(m(x[idx].contiguous(), xd[idx].contiguous()), full[idx])
+    cfg = m._cfg
+    want, _, _ = oracle.informer_forward(cfg, blobs.pack_informer(ck, cfg), x[idx].cpu().numpy(),
+                                         xd[idx].cpu().numpy())
+    assert np.abs(full[idx].cpu().numpy() - want).max() < TOL_PRED
+    # delta-NMSE vs the checker on the same sample, in dB
+    truth = cet.LoadBatch(noisy[:, 25:30])[idx.cpu()].numpy()
+    def nmse(p):
+        return 10 * np.log10(((truth - p) ** 2).sum() / (truth ** 2).sum())
+    assert abs(nmse(full[idx].cpu().numpy()) - nmse(want)) < 0.05

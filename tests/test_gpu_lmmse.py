@@ -1,0 +1,121 @@
+"""Parity of the HIP LMMSE equalizer with the float64 CPU checker (PARITY UNPINNED: the
+reference holds no vector for this path; see oracle/cet_oracle.c)."""
+import numpy as np
+import pytest
+import torch
+
+import channelestimationtransformer_amd as cet
+from channelestimationtransformer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+# complex64 Gram + Cholesky vs float64: relative tolerance on well-conditioned 16x4 problems
+RTOL = 2e-4
+
+
+def run(y, H, no, direct=False):
+    no_t = torch.from_numpy(no).cuda() if isinstance(no, np.ndarray) else no
+    x, ne = cet.lmmse(torch.from_numpy(y).cuda(), torch.from_numpy(H).cuda(), no_t, direct=direct)
+    return x.cpu().numpy(), ne.cpu().numpy()
+
+
+def close(a, b):
+    return np.abs(a - b).max() <= RTOL * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("Nr,Ns", [(16, 4), (16, 2), (16, 1), (8, 4), (8, 2), (8, 1), (4, 4), (4, 2),
+                                   (4, 1), (2, 2), (2, 1)])
+@pytest.mark.parametrize("N", [1, 63, 64, 1000, 4099])
+def test_all_shapes_ragged_sizes(oracle, Nr, Ns, N):
+    y, H, _ = synth.lmmse_problem(N, Nr, Ns, 0.1, seed=N + Nr)
+    want_x, want_ne = oracle.lmmse(y, H, 0.1)
+    for direct in (False, True):
+        x, ne = run(y, H, 0.1, direct)
+        assert close(x, want_x) and close(ne, want_ne), f"direct={direct}"
+
+
+def test_noise_modes(oracle):
+    rng = np.random.default_rng(0)
+    y, H, _ = synth.lmmse_problem(3000, 16, 4, 0.1, seed=1)
+    per_re = rng.uniform(0.02, 1.0, 3000).astype(np.float32)
+    per_rx = rng.uniform(0.02, 1.0, (3000, 16)).astype(np.float32)
+    for no in (per_re, per_rx):
+        want_x, want_ne = oracle.lmmse(y, H, no)
+        for direct in (False, True):
+            x, ne = run(y, H, no, direct)
+            assert close(x, want_x) and close(ne, want_ne)
+
+
+def test_known_answers_and_edge_cases():
+    N, n = 70, 4
+    H = np.tile(np.eye(n, dtype=np.complex64)[None], (N, 1, 1))
+    y = (np.arange(N * n).reshape(N, n) % 7 + 1j).astype(np.complex64)
+    x, ne = run(y, H, 0.25)
+    assert np.allclose(x, y, atol=1e-5) and np.allclose(ne, 0.25, atol=1e-6)
+    g = np.array([2.0, 0.5j, -1.0, 3.0 + 4.0j], dtype=np.complex64)
+    H = np.tile(np.diag(g)[None], (N, 1, 1)).astype(np.complex64)
+    x, ne = run(y, H, 0.5)
+    assert np.allclose(x, y / g, atol=1e-4) and np.allclose(ne, 0.5 / np.abs(g) ** 2, rtol=1e-4)
+    H = np.ones((N, 4, 2), np.complex64)  # rank deficient, regularised by no > 0
+    x, ne = run(np.ones((N, 4), np.complex64), H, 0.1)
+    assert np.isfinite(x).all() and np.isfinite(ne).all()
+    e = torch.empty(0, 16, dtype=torch.complex64, device="cuda")
+    x0, ne0 = cet.lmmse(e, torch.empty(0, 16, 4, dtype=torch.complex64, device="cuda"), 0.1)
+    assert x0.shape == (0, 4) and ne0.shape == (0, 4)
+
+
+def test_snr_extremes(oracle):
+    for no in (1e-4, 10.0):
+        y, H, _ = synth.lmmse_problem(2000, 16, 4, no, seed=7)
+        want_x, want_ne = oracle.lmmse(y, H, no)
+        x, ne = run(y, H, no)
+        assert np.abs(x - want_x).max() <= 5e-4 * max(1.0, np.abs(want_x).max())
+        assert np.abs(ne - want_ne).max() <= 5e-4 * np.abs(want_ne).max()
+
+
+def test_tiled_equals_direct_at_scale():
+    """2^21 REs (1.4 GB of H+y): the two independent kernels agree, QPSK decisions recover
+    the transmitted symbols at this SNR, and a sub-range call returns the same bits."""
+    N = 1 << 21
+    g = torch.Generator(device="cuda").manual_seed(0)
+    H = torch.view_as_complex(torch.randn(N, 16, 4, 2, device="cuda", generator=g) * 0.5 ** 0.5)
+    xs = torch.view_as_complex((torch.randint(0, 2, (N, 4, 2), device="cuda", generator=g).float() * 2 - 1) * 0.5 ** 0.5)
+    noise = torch.view_as_complex(torch.randn(N, 16, 2, device="cuda", generator=g) * (0.05 / 2) ** 0.5)
+    y = torch.einsum("nrs,ns->nr", H, xs) + noise
+    x1, ne1 = cet.lmmse(y, H, 0.05)
+    x2, ne2 = cet.lmmse(y, H, 0.05, direct=True)
+    assert (x1 - x2).abs().max() < 1e-4 and (ne1 - ne2).abs().max() < 1e-5
+    ber = ((x1.real > 0) != (xs.real > 0)).float().mean() + ((x1.imag > 0) != (xs.imag > 0)).float().mean()
+    assert ber < 1e-3
+    lo, hi = 12345, 12345 + 5000
+    x3, _ = cet.lmmse(y[lo:hi], H[lo:hi], 0.05)
+    assert torch.equal(x3, x1[lo:hi])
+
+
+def test_equalizer_object_on_the_reference_geometry(oracle):
+    """`LMMSEEqualizer(rg, sm)([y, h_hat, err_var, no])` with the grid of
+    LocalSimulations/EndtoEndtest.py:50-59 (4 rx antennas, 2 streams, 14 symbols, fft 76)."""
+    rg = cet.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=1,
+                          num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                          dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[0])
+    sm = cet.StreamManagement(np.array([[1]]), 2)
+    equ = cet.LMMSEEqualizer(rg, sm)
+    rng = np.random.default_rng(0)
+    b = 3
+    h = (rng.standard_normal((b, 1, 4, 1, 2, 14, 64)) + 1j * rng.standard_normal((b, 1, 4, 1, 2, 14, 64))).astype(np.complex64)
+    y = (rng.standard_normal((b, 1, 4, 14, 76)) + 1j * rng.standard_normal((b, 1, 4, 14, 76))).astype(np.complex64)
+    no = 0.2
+    x_hat, no_eff = equ([torch.from_numpy(y).cuda(), torch.from_numpy(h).cuda(), 0., no])
+    assert x_hat.shape == (b, 1, 2, 832) and no_eff.shape == (b, 1, 2, 832)
+    sc = rg.effective_subcarrier_ind
+    yd = y[:, 0][:, :, 1:, :][:, :, :, sc].transpose(0, 2, 3, 1).reshape(-1, 4)
+    hd = h[:, 0, :, 0][:, :, :, 1:, :].transpose(0, 3, 4, 1, 2).reshape(-1, 4, 2)
+    wx, wne = oracle.lmmse(yd, hd, no)
+    wx = wx.reshape(b, 832, 2).transpose(0, 2, 1)[:, None]
+    wne = wne.reshape(b, 832, 2).transpose(0, 2, 1)[:, None]
+    assert close(x_hat.cpu().numpy(), wx) and close(no_eff.cpu().numpy(), wne)
+    # estimation-error variance folds into a per-antenna noise term
+    ev = 0.05
+    x2, ne2 = equ([torch.from_numpy(y).cuda(), torch.from_numpy(h).cuda(), torch.tensor(ev), no])
+    wx2, wne2 = oracle.lmmse(yd, hd, np.full((yd.shape[0], 4), no + 2 * ev, np.float32))
+    assert close(x2.cpu().numpy(), wx2.reshape(b, 832, 2).transpose(0, 2, 1)[:, None])
