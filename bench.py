@@ -1,0 +1,326 @@
+"""Throughput benchmark of the predictor + LMMSE inference path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload informer|lmmse|lstm|gru|rnn]
+
+One "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM. The default workload is the Transformer predictor forward on 4096 channel
+sequences per GPU (InformerStack, the constructor arguments of LocalSimulations/Predict.py:
+21-38, shipped checkpoint weights). With N > 1 (one process per GPU, launched by
+torch.distributed.run) every rank runs the same per-GPU batch (weak scaling); the only
+collective is one RCCL all-reduce of the NMSE partial sums at the end of the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import channelestimationtransformer_amd as cet  # noqa: E402
+from channelestimationtransformer_amd import blobs, metrics, synth  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# Algorithmic work / bytes per unit (dense contractions only for the FLOP figures).
+INFORMER_FLOP = 8.897e6          # per prediction, default configuration
+RNN_FLOP_PER_STEP = {"lstm": 1.614e6, "gru": 1.213e6, "rnn": 0.410e6}
+LMMSE_BYTES = {(16, 4): 688.0, (8, 4): 368.0, (4, 2): 120.0}
+PEAK_FP32_MFMA_TFLOPS = 157.3    # dense fp32 matrix peak of MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="informer", choices=["informer", "lmmse", "lstm", "gru", "rnn"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (sequences or REs)")
+    ap.add_argument("--pred-len", type=int, default=25, help="rollout horizon of the recurrent workloads")
+    ap.add_argument("--no-attention-maps", action="store_true",
+                    help="informer: do not materialise the attention maps (output_attention=False)")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-secondary", action="store_true")
+    return ap.parse_args()
+
+
+def torch_sd(npz_dict):
+    sd = {}
+    for k, v in npz_dict.items():
+        t = torch.from_numpy(np.array(v))
+        if k.endswith("position_embedding.pe"):
+            full = torch.zeros(1, 5000, t.shape[-1])
+            full[:, :t.shape[1]] = t
+            t = full
+        sd[k] = t
+    return sd
+
+
+def make_informer(output_attention):
+    m = cet.InformerStack(16, 16, 16, 25, 10, 5, 5, 64, 8, 4, 3, 64, 0.05, "full", "fixed", "gelu",
+                          output_attention, True)
+    ck = dict(np.load(os.path.join(GOLDEN, "informer_ckpt.npz")))
+    m.load_state_dict(torch_sd(ck))
+    return m.eval(), ck
+
+
+def make_rnn(kind):
+    name = kind.upper()
+    rk = np.load(os.path.join(GOLDEN, "rnn_ckpt.npz"))
+    sd = {k[len(name) + 1:]: rk[k] for k in rk.files if k.startswith(name + "/")}
+    m = getattr(cet, name)(16, 16, 256, 2)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    return m.eval(), sd
+
+
+def timed_loop(step, steps, warmup, dist_on, dev):
+    """W untimed steps, then exactly K steps between barrier+synchronize pairs. Returns
+    (wall seconds for the K steps, mean per-step device time from HIP events in seconds)."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize(dev)
+    if dist_on:
+        dist.barrier()
+    t1 = time.perf_counter()
+    dev_s = sum(a.elapsed_time(b) for a, b in ev) / steps * 1e-3
+    return t1 - t0, dev_s
+
+
+def cpu_baseline_informer(ck, x, xd, budget_s=15.0):
+    from oracle import pyoracle
+    model_cfg = blobs.make_informer_cfg(16, 16, 16, 25, 10, 5, 64, 8, 4, 3, 64, True, True, "gelu")
+    blob = blobs.pack_informer(ck, model_cfg)
+    threads = pyoracle.num_threads()
+    n = 64
+    t0 = time.perf_counter()
+    pyoracle.informer_forward(model_cfg, blob, x[:n], xd[:n])
+    dt = time.perf_counter() - t0
+    n2 = int(min(x.shape[0], max(n, n * budget_s / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    pyoracle.informer_forward(model_cfg, blob, x[:n2], xd[:n2])
+    dt = time.perf_counter() - t0
+    return {"value": n2 / dt, "unit": "predictions/s", "cores": threads, "kind": "port",
+            "sample": f"{n2} of the benchmark's sequences through oracle/cet_oracle.c "
+                      f"(C restatement, OpenMP over sequences, {threads} threads)"}
+
+
+def cpu_baseline_rnn(kind, sd, x, pred_len, budget_s=15.0):
+    from oracle import pyoracle
+    kid = blobs.RNN_KINDS[kind]
+    blob = blobs.pack_rnn(sd, kid, 16, 16, 256, 2)
+    threads = pyoracle.num_threads()
+    n = 32
+    t0 = time.perf_counter()
+    pyoracle.rnn_rollout(kid, 16, 16, 256, 2, blob, x[:n], pred_len)
+    dt = time.perf_counter() - t0
+    n2 = int(min(x.shape[0], max(n, n * budget_s / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    pyoracle.rnn_rollout(kid, 16, 16, 256, 2, blob, x[:n2], pred_len)
+    dt = time.perf_counter() - t0
+    return {"value": n2 / dt, "unit": "predictions/s", "cores": threads, "kind": "port",
+            "sample": f"{n2} sequences, pred_len {pred_len}, oracle/cet_oracle.c with {threads} threads"}
+
+
+def cpu_baseline_lmmse(Nr, Ns, no, budget_s=12.0):
+    from oracle import pyoracle
+    threads = pyoracle.num_threads()
+    n = 200_000
+    y, H, _ = synth.lmmse_problem(n, Nr, Ns, no, seed=0)
+    t0 = time.perf_counter()
+    pyoracle.lmmse(y, H, no)
+    dt = time.perf_counter() - t0
+    reps = max(1, int(budget_s / max(dt, 1e-3)))
+    t0 = time.perf_counter()
+    for _ in range(min(reps, 20)):
+        pyoracle.lmmse(y, H, no)
+    dt = (time.perf_counter() - t0) / min(reps, 20)
+    return {"value": n / dt, "unit": "REs/s", "cores": threads, "kind": "port",
+            "sample": f"{n} REs {Nr}x{Ns}, float64 C restatement (oracle/cet_oracle.c), {threads} threads"}
+
+
+def lmmse_inputs(N, Nr, Ns, no, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    H = torch.randn(N, Nr, Ns, 2, device=dev, generator=g) * 0.5 ** 0.5
+    bits = torch.randint(0, 2, (N, Ns, 2), device=dev, generator=g).float() * 2 - 1
+    xs = torch.view_as_complex((bits * 0.5 ** 0.5).contiguous())
+    Hc = torch.view_as_complex(H)
+    y = torch.einsum("nrs,ns->nr", Hc, xs)
+    y = y + torch.view_as_complex(torch.randn(N, Nr, 2, device=dev, generator=g) * (no / 2) ** 0.5)
+    return y.contiguous(), Hc, xs
+
+
+def main():
+    args = parse()
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist_on:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world
+
+    out = {"n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    extra = {}
+
+    if args.workload == "informer":
+        B = args.batch or 4096
+        want_maps = not args.no_attention_maps
+        model, ck = make_informer(want_maps)
+        noisy, _ = synth.channel_histories(B, seed=rank)
+        x = cet.LoadBatch(noisy[:, :25]).to(dev)
+        xd = cet.decoder_input(x, 10, 5)
+        truth = cet.LoadBatch(noisy[:, 25:30]).to(dev)
+        holder = {}
+
+        def step():
+            r = model(x, xd)
+            holder["pred"] = r[0] if want_maps else r
+
+        wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
+        sums = metrics.nmse_partial_sums(holder["pred"], truth)
+        metrics.all_reduce_sums(sums)  # the path's only collective (RCCL)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if dist_on:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t)
+        achieved = INFORMER_FLOP * B / dev_s / 1e12
+        out.update({
+            "metric": "channel predictions/s (Transformer predictor forward)",
+            "value": B * n_gpus * args.steps / wall, "unit": "predictions/s",
+            "ms_per_step": wall / args.steps * 1e3, "dtype": "f32",
+            "config": {"workload": "InformerStack forward, enc_in=16 seq_len=25 label_len=10 pred_len=5 "
+                                   "d_model=64 n_heads=8 e_layers=4 d_layers=3 d_ff=64, "
+                                   f"output_attention={want_maps}, shipped checkpoint",
+                       "batch_per_gpu": B, "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "informer_kernel", "kernel_ms": dev_s * 1e3,
+                         "flop_per_launch": INFORMER_FLOP * B},
+            "nmse_db_per_slot": [round(float(v), 3) for v in metrics.nmse_db(sums).cpu()],
+        })
+        if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_informer(ck, x.cpu().numpy(), xd.cpu().numpy())
+
+        if rank == 0 and n_gpus == 1 and not args.skip_secondary:
+            # secondary lines: the other kernels of the path, shorter runs
+            model2, _ = make_informer(not want_maps)
+            def step2():
+                model2(x, xd)
+            w2, d2 = timed_loop(step2, max(5, args.steps // 5), 2, False, dev)
+            extra[f"informer_output_attention_{not want_maps}"] = {
+                "predictions_per_s": B / d2, "kernel_ms": d2 * 1e3,
+                "mfma_frac": INFORMER_FLOP * B / d2 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+            N = 1 << 23
+            y, H, _xs = lmmse_inputs(N, 16, 4, 0.1, dev, 0)
+            def step3():
+                cet.lmmse(y, H, 0.1)
+            w3, d3 = timed_loop(step3, 10, 2, False, dev)
+            extra["lmmse_16x4"] = {"REs_per_s": N / d3, "kernel_ms": d3 * 1e3, "N": N,
+                                   "hbm_GBps": 688.0 * N / d3 / 1e9,
+                                   "hbm_frac": 688.0 * N / d3 / 1e9 / PEAK_HBM_GBS}
+            del y, H
+            for kind in ("lstm", "gru", "rnn"):
+                rm, _sd = make_rnn(kind)
+                nb, _ = synth.channel_histories(8192, seed=1)
+                xr = cet.LoadBatch(nb[:, :25]).to(dev)
+                def step4():
+                    rm.test_data(xr, 5, dev)
+                w4, d4 = timed_loop(step4, 5, 1, False, dev)
+                fl = RNN_FLOP_PER_STEP[kind] * 29 * 8192
+                extra[f"{kind}_rollout_B8192_pred5"] = {
+                    "predictions_per_s": 8192 / d4, "kernel_ms": d4 * 1e3,
+                    "mfma_frac": fl / d4 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+
+    elif args.workload == "lmmse":
+        Nr, Ns, no = 16, 4, 0.1
+        N = args.batch or 3276 * 14 * 1024  # 46,964,736 REs = 32.3 GB of operands
+        y, H, xs = lmmse_inputs(N, Nr, Ns, no, dev, rank)
+        holder = {}
+
+        def step():
+            holder["x"], holder["ne"] = cet.lmmse(y, H, no)
+
+        wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
+        bits = metrics.qpsk_bit_errors(holder["x"], xs)
+        metrics.all_reduce_sums(bits)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if dist_on:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t)
+        gbs = LMMSE_BYTES[(Nr, Ns)] * N / dev_s / 1e9
+        out.update({
+            "metric": "LMMSE-equalized REs/s", "value": N * n_gpus * args.steps / wall, "unit": "REs/s",
+            "ms_per_step": wall / args.steps * 1e3, "dtype": "complex64 (f32 arithmetic)",
+            "config": {"workload": f"LMMSE {Nr}x{Ns}, {N} REs per GPU (3276 sc x 14 sym x 1024 slots), no=0.1",
+                       "parallelism": f"dp{n_gpus}"},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": gbs / PEAK_HBM_GBS, "traffic": None, "kernel": "lmmse_tiled<16,4,2>",
+                         "kernel_ms": dev_s * 1e3, "bytes_per_launch": LMMSE_BYTES[(Nr, Ns)] * N},
+            "ber": float(bits[0] / bits[1]),
+        })
+        if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_lmmse(Nr, Ns, no)
+
+    else:
+        kind = args.workload
+        B = args.batch or 8192
+        P = args.pred_len
+        model, sd = make_rnn(kind)
+        noisy, _ = synth.channel_histories(B, T=25 + 5, seed=rank)
+        x = cet.LoadBatch(noisy[:, :25]).to(dev)
+        holder = {}
+
+        def step():
+            holder["pred"] = model.test_data(x, P, dev)
+
+        wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if dist_on:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t)
+        flop = RNN_FLOP_PER_STEP[kind] * (24 + P) * B
+        achieved = flop / dev_s / 1e12
+        out.update({
+            "metric": f"channel predictions/s ({kind.upper()} rollout)",
+            "value": B * n_gpus * args.steps / wall, "unit": "predictions/s",
+            "ms_per_step": wall / args.steps * 1e3, "dtype": "f32",
+            "config": {"workload": f"{kind.upper()}(16,16,256,2).test_data, seq_len 25, pred_len {P}, shipped checkpoint",
+                       "batch_per_gpu": B, "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "rnn_rollout_kernel", "kernel_ms": dev_s * 1e3, "flop_per_launch": flop},
+        })
+        if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_rnn(kind, sd, x.cpu().numpy(), P)
+
+    if extra:
+        out["secondary"] = extra
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,8 @@ class LMMSEEqualizer:
             if ev.dim() > 0:
                 ev = torch.broadcast_to(ev, h_hat.shape)[:, 0].index_select(4, sym)
                 ev = ev.permute(0, 4, 5, 1, 2, 3).reshape(b, len(sym), len(sc), ant, ntx * nst).sum(-1)
+            else:
+                ev = ev * (ntx * nst)  # the same variance on every stream's estimate
             nb = no_t.reshape(b, 1, 1, -1) if no_t.dim() > 0 else no_t
             noise = torch.broadcast_to(ev + nb, (b, len(sym), len(sc), ant)).reshape(N, ant).contiguous()
         x, ne = lmmse(yd.reshape(N, ant), hd.reshape(N, ant, ntx * nst), noise)

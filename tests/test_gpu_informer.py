@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 # fp32 throughout; the reference itself reproduces its stored outputs to ~1.2e-6.
 TOL_PRED = 2e-5   # max-abs on outputs of magnitude <= ~2.5
 TOL_STAGE = 5e-5  # max-abs on internal activations (LayerNorm outputs, magnitude <= ~10)
-TOL_ATTN = 5e-6   # attention probabilities
+TOL_ATTN = 2e-5   # attention probabilities (softmax outputs after up to 7 layers)
 
 
 def to_torch_sd(d):
