@@ -35,6 +35,21 @@ PEAK_FP32_MFMA_TFLOPS = 157.3    # dense fp32 matrix peak of MI355X
 PEAK_HBM_GBS = 8000.0
 
 
+def measured_traffic(workload, units, per_unit_key=None):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes), scaled to this launch's unit count.
+    None when no profile of this workload is on disk."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_hbm_traffic.json"):
+            with open(os.path.join(pdir, name)) as f:
+                d = json.load(f)
+            if workload in d and d[workload].get("units"):
+                best = d[workload]["traffic_bytes_per_launch"] / d[workload]["units"] * units
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,7 +229,8 @@ def main():
                                    f"output_attention={want_maps}, shipped checkpoint",
                        "batch_per_gpu": B, "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": measured_traffic("informer" if want_maps else "informer_nomaps", B),
                          "kernel": "informer_kernel", "kernel_ms": dev_s * 1e3,
                          "flop_per_launch": INFORMER_FLOP * B},
             "nmse_db_per_slot": [round(float(v), 3) for v in metrics.nmse_db(sums).cpu()],
@@ -275,7 +291,8 @@ def main():
             "config": {"workload": f"LMMSE {Nr}x{Ns}, {N} REs per GPU (3276 sc x 14 sym x 1024 slots), no=0.1",
                        "parallelism": f"dp{n_gpus}"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": gbs / PEAK_HBM_GBS, "traffic": None, "kernel": "lmmse_tiled<16,4,2>",
+                         "frac": gbs / PEAK_HBM_GBS, "traffic": measured_traffic("lmmse", N),
+                         "kernel": "lmmse_tiled<16,4,2>",
                          "kernel_ms": dev_s * 1e3, "bytes_per_launch": LMMSE_BYTES[(Nr, Ns)] * N},
             "ber": float(bits[0] / bits[1]),
         })
