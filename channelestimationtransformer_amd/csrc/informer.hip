@@ -19,6 +19,7 @@
 // as they stand; two heads share one 16-feature output tile by zeroing the other head's
 // rows of the V^T operand.
 // All arithmetic is fp32 (MFMA f32 = exact fmaf chains); exp/erf/sqrt are the accurate forms.
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -34,7 +35,6 @@ constexpr int DM = 64;    // d_model
 constexpr int NHEAD = 8;  // heads (head dim 8)
 constexpr int LDW = 68;   // LDS row stride in floats (64 + 4: conflict-free fragment reads)
 constexpr int MAXROWS = 32;
-constexpr int LDS_ROWS = 3 * MAXROWS;  // Q | K | V regions, contiguous
 
 struct Dims {
   int enc_in, dec_in, c_out, seq_len, label_len, pred_len;
@@ -43,6 +43,7 @@ struct Dims {
   int attn_len[64];    // their sequence lengths
   int n_taps;
   int tap_rows[128];
+  int mem_rows;        // rows of the concatenated encoder outputs (cross-attention keys)
 };
 
 struct KArgs {
@@ -56,6 +57,7 @@ struct KArgs {
   int enc_in, dec_in, c_out, seq_len, label_len, pred_len;
   int n_enc, distil, activation, d_layers;
   int enc_layers[8];
+  int region_rows;  // rows of each of the three LDS regions (Q | K | V)
 };
 
 #define DEV __device__ __forceinline__
@@ -94,12 +96,17 @@ DEV void linear64(const float* __restrict__ W, const float* __restrict__ bias, c
   }
 }
 
+// Rows [0, nrows) of the tiles go to LDS; rows of the padded tiles beyond that are dropped
+// (the regions are sized to the sequence, not to whole tiles).
 template <int RT>
-DEV void store_rows(float* buf, const Lane ln, const f32x4 (&v)[2][4]) {
+DEV void store_rows(float* buf, const Lane ln, const f32x4 (&v)[2][4], int nrows) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt) {
+    if (16 * rt + ln.c < nrows) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) st4(buf + (16 * rt + ln.c) * LDW + 16 * m + 4 * ln.g, v[rt][m]);
+      for (int m = 0; m < 4; ++m) st4(buf + (16 * rt + ln.c) * LDW + 16 * m + 4 * ln.g, v[rt][m]);
+    }
+  }
 }
 
 // torch.nn.LayerNorm(64), eps 1e-5, over the feature axis (in-lane 16 values + lane groups).
@@ -252,7 +259,9 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
     for (int kt = 0; kt < RK; ++kt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float v = Vb[(16 * kt + 4 * ln.g + i) * LDW + 16 * hp + ln.c];
+        int vr = 16 * kt + 4 * ln.g + i;
+        vr = vr < Lk ? vr : Lk - 1;  // padded keys carry probability 0; stay inside the region
+        const float v = Vb[vr * LDW + 16 * hp + ln.c];
         const float v0 = upper ? 0.f : v;
         const float v1 = upper ? v : 0.f;
 #pragma unroll
@@ -273,20 +282,20 @@ constexpr int SZ_FFN = 2 * (DM * DM + DM);
 // AttentionLayer (attn.py:140-156): projections -> LDS, attention, output projection.
 // xq: query-side input, xkv: key/value-side input (T layout). Result in `o`.
 template <int RQ, int RK>
-DEV void attention_block(const float* __restrict__ w, float* smem, const Lane ln,
+DEV void attention_block(const float* __restrict__ w, float* smem, int R, const Lane ln,
                          const f32x4 (&xq)[2][4], const f32x4 (&xkv)[2][4], int Lq, int Lk,
                          bool causal, float* amap, f32x4 (&o)[2][4]) {
-  float* Qb = smem;
-  float* Kb = smem + MAXROWS * LDW;
-  float* Vb = smem + 2 * MAXROWS * LDW;
+  float* Qb = smem;  // R rows each; a padded tile read may run into the next region (finite data)
+  float* Kb = smem + R * LDW;
+  float* Vb = smem + 2 * R * LDW;
   f32x4 t[2][4];
   __syncthreads();  // earlier readers of the Q/K/V regions are done
   linear64<RQ>(w, w + DM * DM, ln, xq, t);
-  store_rows<RQ>(Qb, ln, t);
+  store_rows<RQ>(Qb, ln, t, Lq);
   linear64<RK>(w + (DM * DM + DM), w + (DM * DM + DM) + DM * DM, ln, xkv, t);
-  store_rows<RK>(Kb, ln, t);
+  store_rows<RK>(Kb, ln, t, Lk);
   linear64<RK>(w + 2 * (DM * DM + DM), w + 2 * (DM * DM + DM) + DM * DM, ln, xkv, t);
-  store_rows<RK>(Vb, ln, t);
+  store_rows<RK>(Vb, ln, t, Lk);
   __syncthreads();
   f32x4 ctx[2][4];
   attention<RQ, RK>(Qb, Kb, Vb, Lq, Lk, causal, ln, ctx, amap);
@@ -311,10 +320,10 @@ DEV void ffn(const float* __restrict__ w, const Lane ln, int activation, const f
 // EncoderLayer.forward (encoder.py:37-53). Block: attn | ffn | norm1 g,b | norm2 g,b.
 constexpr int SZ_ENC_LAYER = SZ_ATTN + SZ_FFN + 4 * DM;
 template <int RT>
-DEV void encoder_layer(const float* __restrict__ w, float* smem, const Lane ln, int L,
+DEV void encoder_layer(const float* __restrict__ w, float* smem, int R, const Lane ln, int L,
                        int activation, float* amap, f32x4 (&x)[2][4]) {
   f32x4 y[2][4];
-  attention_block<RT, RT>(w, smem, ln, x, x, L, L, false, amap, y);
+  attention_block<RT, RT>(w, smem, R, ln, x, x, L, L, false, amap, y);
   add_into<RT>(x, y);
   const float* nw = w + SZ_ATTN + SZ_FFN;
   layer_norm<RT>(x, nw, nw + DM, ln);
@@ -327,14 +336,14 @@ DEV void encoder_layer(const float* __restrict__ w, float* smem, const Lane ln, 
 // Block: self attn | cross attn | ffn | norm1 | norm2 | norm3.
 constexpr int SZ_DEC_LAYER = 2 * SZ_ATTN + SZ_FFN + 6 * DM;
 template <int RD, int RM>
-DEV void decoder_layer(const float* __restrict__ w, float* smem, const Lane ln, int Ld, int Lm,
-                       int activation, const f32x4 (&mem)[2][4], f32x4 (&x)[2][4]) {
+DEV void decoder_layer(const float* __restrict__ w, float* smem, int R, const Lane ln, int Ld,
+                       int Lm, int activation, const f32x4 (&mem)[2][4], f32x4 (&x)[2][4]) {
   f32x4 y[2][4];
   const float* nw = w + 2 * SZ_ATTN + SZ_FFN;
-  attention_block<RD, RD>(w, smem, ln, x, x, Ld, Ld, true, nullptr, y);
+  attention_block<RD, RD>(w, smem, R, ln, x, x, Ld, Ld, true, nullptr, y);
   add_into<RD>(x, y);
   layer_norm<RD>(x, nw, nw + DM, ln);
-  attention_block<RD, RM>(w + SZ_ATTN, smem, ln, x, mem, Ld, Lm, false, nullptr, y);
+  attention_block<RD, RM>(w + SZ_ATTN, smem, R, ln, x, mem, Ld, Lm, false, nullptr, y);
   add_into<RD>(x, y);
   layer_norm<RD>(x, nw + 2 * DM, nw + 3 * DM, ln);
   ffn<RD>(w + 2 * SZ_ATTN, ln, activation, x, y);
@@ -347,12 +356,12 @@ DEV void decoder_layer(const float* __restrict__ w, float* smem, const Lane ln, 
 // Block: w[3][64][64] (tap-major) | bias | alpha | beta.
 constexpr int SZ_DISTIL = 3 * DM * DM + 3 * DM;
 template <int RT>  // tiles covering L + 2 conv outputs
-DEV int distil(const float* __restrict__ w, float* smem, const Lane ln, int L,
+DEV int distil(const float* __restrict__ w, float* smem, int R, const Lane ln, int L,
                f32x4 (&x)[2][4]) {
-  float* Xb = smem;                   // L input rows
-  float* Yb = smem + MAXROWS * LDW;   // L + 2 activated conv outputs
+  float* Xb = smem;            // L input rows
+  float* Yb = smem + R * LDW;  // L + 2 activated conv outputs (R + L + 2 <= 3 R)
   __syncthreads();
-  store_rows<RT>(Xb, ln, x);
+  store_rows<RT>(Xb, ln, x, L);
   __syncthreads();
   const int Lc = L + 2;
   f32x4 y[2][4];
@@ -390,7 +399,7 @@ DEV int distil(const float* __restrict__ w, float* smem, const Lane ln, int L,
       y[rt][mo] = acc;
     }
   }
-  store_rows<RT>(Yb, ln, y);
+  store_rows<RT>(Yb, ln, y, Lc);
   __syncthreads();
   const int Lo = (Lc - 1) / 2 + 1;
 #pragma unroll
@@ -465,7 +474,7 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
 DEV void move_rows(float* smem, const Lane ln, const f32x4 (&x)[2][4], int first, int n, int dst,
                    f32x4 (&into)[2][4]) {
   __syncthreads();
-  store_rows<2>(smem, ln, x);
+  store_rows<2>(smem, ln, x, first + n);
   __syncthreads();
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
@@ -478,14 +487,17 @@ DEV void move_rows(float* smem, const Lane ln, const f32x4 (&x)[2][4], int first
   }
 }
 
-__global__ __launch_bounds__(64) void informer_kernel(const KArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[LDS_ROWS * LDW];
+// WPE: waves per SIMD the register allocation must allow (occupancy is then set by LDS).
+template <int WPE>
+__global__ __launch_bounds__(64, WPE) void informer_kernel(const KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x;
   const Lane ln{lane & 15, lane >> 4};
   const int b = blockIdx.x;
+  const int R = a.region_rows;
 
   // Rows the padded 16-row tiles may touch must hold finite numbers from the start.
-  for (int i = lane; i < LDS_ROWS * LDW / 4; i += 64) st4(smem + 4 * i, zero4());
+  for (int i = lane; i < 3 * R * LDW / 4; i += 64) st4(smem + 4 * i, zero4());
 
   const float* w = a.w;
   float* taps = a.taps;
@@ -522,13 +534,13 @@ __global__ __launch_bounds__(64) void informer_kernel(const KArgs a) {
         amap = attn + (size_t)b * NHEAD * L * L;
         attn += (size_t)a.B * NHEAD * L * L;
       }
-      if (L > 16) encoder_layer<2>(w, smem, ln, L, a.activation, amap, x);
-      else encoder_layer<1>(w, smem, ln, L, a.activation, amap, x);
+      if (L > 16) encoder_layer<2>(w, smem, R, ln, L, a.activation, amap, x);
+      else encoder_layer<1>(w, smem, R, ln, L, a.activation, amap, x);
       w += SZ_ENC_LAYER;
       tap<2>(taps, a.B, b, L, ln, x);
       if (a.distil && l < el - 1) {
-        if (L + 2 > 16) L = distil<2>(w, smem, ln, L, x);
-        else L = distil<1>(w, smem, ln, L, x);
+        if (L + 2 > 16) L = distil<2>(w, smem, R, ln, L, x);
+        else L = distil<1>(w, smem, R, ln, L, x);
         w += SZ_DISTIL;
         tap<2>(taps, a.B, b, L, ln, x);
       }
@@ -553,11 +565,11 @@ __global__ __launch_bounds__(64) void informer_kernel(const KArgs a) {
   }
   for (int l = 0; l < a.d_layers; ++l) {
     if (Ld > 16) {
-      if (mem_rows > 16) decoder_layer<2, 2>(w, smem, ln, Ld, mem_rows, a.activation, mem, x);
-      else decoder_layer<2, 1>(w, smem, ln, Ld, mem_rows, a.activation, mem, x);
+      if (mem_rows > 16) decoder_layer<2, 2>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
+      else decoder_layer<2, 1>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
     } else {
-      if (mem_rows > 16) decoder_layer<1, 2>(w, smem, ln, Ld, mem_rows, a.activation, mem, x);
-      else decoder_layer<1, 1>(w, smem, ln, Ld, mem_rows, a.activation, mem, x);
+      if (mem_rows > 16) decoder_layer<1, 2>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
+      else decoder_layer<1, 1>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
     }
     w += SZ_DEC_LAYER;
     tap<2>(taps, a.B, b, Ld, ln, x);
@@ -648,6 +660,7 @@ static bool plan(const cet_informer_cfg& c, Dims& d) {
     inp_len /= 2;
   }
   if (mem_rows > MAXROWS) return false;
+  d.mem_rows = mem_rows;
   d.tap_rows[d.n_taps++] = mem_rows;
   d.tap_rows[d.n_taps++] = Ld;
   for (int l = 0; l < c.d_layers; ++l) d.tap_rows[d.n_taps++] = Ld;
@@ -778,7 +791,22 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   a.n_enc = m->d.n_enc; a.distil = m->d.distil; a.activation = m->d.activation;
   a.d_layers = m->d.d_layers;
   for (int i = 0; i < 8; ++i) a.enc_layers[i] = m->d.enc_layers[i];
-  hipLaunchKernelGGL(informer_kernel, dim3((unsigned)B), dim3(64), 0, stream, a);
+  // LDS: three regions of R rows (Q | K | V; also the conv / max-pool staging, which needs
+  // L + (L + 2) rows, and the 32-row staging of move_rows).
+  const int Ld = m->d.label_len + m->d.pred_len;
+  int R = m->d.seq_len > Ld ? m->d.seq_len : Ld;
+  if (R < m->d.mem_rows) R = m->d.mem_rows;
+  if (R < 12) R = 12;
+  a.region_rows = R;
+  const size_t lds = (size_t)3 * R * LDW * sizeof(float);
+  static const int wpe = [] {
+    const char* e = getenv("CET_INFORMER_WPE");
+    return e ? atoi(e) : 2;
+  }();
+  if (wpe == 1)
+    hipLaunchKernelGGL(informer_kernel<1>, dim3((unsigned)B), dim3(64), lds, stream, a);
+  else
+    hipLaunchKernelGGL(informer_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream, a);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
