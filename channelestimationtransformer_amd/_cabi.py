@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcet.so")
+# CET_LIB selects another build of the same ABI (the profiling build of tools/)
+LIB_PATH = os.environ.get("CET_LIB") or os.path.join(_HERE, "csrc", "libcet.so")
 
 ERR_NAMES = {0: "CET_OK", 1: "CET_ERR_INVALID_ARG", 2: "CET_ERR_UNSUPPORTED", 3: "CET_ERR_HIP",
              4: "CET_ERR_ALLOC", 5: "CET_ERR_BLOB_SIZE"}

@@ -19,6 +19,7 @@
 // as they stand; two heads share one 16-feature output tile by zeroing the other head's
 // rows of the V^T operand.
 // All arithmetic is fp32 (MFMA f32 = exact fmaf chains); exp/erf/sqrt are the accurate forms.
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -46,6 +47,15 @@ struct Dims {
   int mem_rows;        // rows of the concatenated encoder outputs (cross-attention keys)
 };
 
+// One step of the encoder stack, in execution order (built on the host).
+enum { OP_LAYER = 0, OP_DISTIL = 1, OP_NORM_APPEND = 2, OP_SLICE = 3 };
+struct Op {
+  unsigned char type;
+  unsigned char L;     // rows on entry
+  unsigned char a, b;  // NORM_APPEND: a = row offset in the memory; SLICE: a = first row, b = rows kept
+};
+constexpr int MAX_OPS = 80;
+
 struct KArgs {
   const float* w;  // device blob, execution order
   const float* x_enc;
@@ -58,6 +68,11 @@ struct KArgs {
   int n_enc, distil, activation, d_layers;
   int enc_layers[8];
   int region_rows;  // rows of each of the three LDS regions (Q | K | V)
+  int n_ops, n_ops2;  // encoder steps; the first n_ops2 of them touch more than 16 rows
+  int mem_rows;
+  Op ops[MAX_OPS];
+  int ablate;       // timing experiments only (CET_INFORMER_ABLATE): skips parts, wrong results
+  unsigned long long* prof;  // profiling build only
 };
 
 #define DEV __device__ __forceinline__
@@ -69,28 +84,118 @@ DEV f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// Sum / max over the four lane groups g (lanes c, c+16, c+32, c+48), result in all four.
+// v_permlane16_swap / v_permlane32_swap exchange 16- and 32-lane halves inside the VALU, so
+// the reductions of softmax and LayerNorm never take the LDS round trip of a ds_bpermute.
+// With vdst = src = v the two results hold v of (own half, other half) in every lane.
+// The results are copied into scalars before the bit cast: a __builtin_bit_cast applied
+// directly to an element of the returned vector reads element 0 for both (hipcc, ROCm 7.2).
+DEV void swap16(float v, float& lo, float& hi) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  lo = __builtin_bit_cast(float, r0);
+  hi = __builtin_bit_cast(float, r1);
+}
+DEV void swap32(float v, float& lo, float& hi) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  lo = __builtin_bit_cast(float, r0);
+  hi = __builtin_bit_cast(float, r1);
+}
+DEV float group_sum(float v) {
+  float a, b;
+  swap16(v, a, b);
+  swap32(a + b, a, b);
+  return a + b;
+}
+DEV float group_max(float v) {
+  float a, b;
+  swap16(v, a, b);
+  swap32(fmaxf(a, b), a, b);
+  return fmaxf(a, b);
+}
+
 struct Lane {
   int c;  // lane & 15 : row inside a tile (B operand / C column)
   int g;  // lane >> 4 : k group / C row block
+  int ablate;  // timing-experiment mask, 0 in production
+  unsigned wo;  // c * 64 + 4 * g : this lane's offset inside a 16-row block of a [.][64] matrix
+#ifdef CET_PROF
+  unsigned long long* prof;  // this wave's stamp trace, or null when the wave is not sampled
+  int* pidx;                 // next free entry of the trace
+#endif
 };
 
+// Phase stamps of the profiling build (libcet_prof.so): a few sampled waves append
+// (clock << 4 | category) to a trace in global memory; the host sums the intervals per
+// category. Compiles to nothing in the product library.
+#ifdef CET_PROF
+constexpr int PROF_SAMPLES = 16, PROF_MAXM = 1024;
+#define PROF_MARK(ln, cat)                                                              \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                       \
+    if ((ln).prof && (threadIdx.x & 63) == 0 && *(ln).pidx < PROF_MAXM)                 \
+      (ln).prof[*(ln).pidx] = (now_ << 4) | (unsigned long long)(cat);                  \
+    *(ln).pidx += 1;                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#else
+#define PROF_MARK(ln, cat) do { } while (0)
+#endif
+enum { P_EMBED = 0, P_QKV, P_ATTN, P_OPROJ, P_ADDLN, P_FFN, P_DISTIL, P_MOVE, P_PROJ, P_OTHER, P_N };
+
 // out^T[rt][mo] = W[64 x 64] * in^T  (+ bias). W row-major [out][in], bias[out].
-template <int RT>
-DEV void linear64(const float* __restrict__ W, const float* __restrict__ bias, const Lane ln,
-                  const f32x4 (&in)[2][4], f32x4 (&out)[2][4]) {
+// All 16 weight fragments (and the bias) of the product are requested before the first MFMA:
+// the wave then pays one load latency per product, and the remaining fragments land while the
+// matrix pipe works (left to itself the compiler, which is register-bound at two waves per
+// SIMD, sinks every load next to its first use). Addresses are a uniform base plus one
+// per-lane offset, so the loads need no vector address arithmetic.
+struct NormParams {
+  f32x4 gm[4], bt[4];  // gamma / beta of this lane's 16 features
+};
+DEV void load_norm(NormParams& n, const float* __restrict__ gamma_beta, const Lane ln) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    n.gm[m] = ld4(gamma_beta + 16 * m + 4 * ln.g);
+    n.bt[m] = ld4(gamma_beta + DM + 16 * m + 4 * ln.g);
+  }
+}
+
+// Weight fragments of one 64x64 product (A operands of all 64 MFMAs per row tile) + bias.
+struct WFrag {
+  f32x4 a[4][4], bv[4];
+};
+// Requests the fragments of W[64][64] (row-major) and bias[64]. The sched_barrier pins the
+// requests where they are written: the kernel's layer schedules issue them one product ahead
+// of their use, which the register-bound compiler would otherwise undo.
+DEV void wload(WFrag& f, const float* __restrict__ W, const Lane ln, NormParams* norm = nullptr,
+               const float* __restrict__ norm_w = nullptr) {
+  const float* bias = W + DM * DM;
 #pragma unroll
   for (int mo = 0; mo < 4; ++mo) {
-    f32x4 a[4];
+    const float* Wm = W + 16 * mo * DM;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) a[mi] = ld4(W + (16 * mo + ln.c) * DM + 16 * mi + 4 * ln.g);
-    const f32x4 bv = ld4(bias + 16 * mo + 4 * ln.g);
+    for (int mi = 0; mi < 4; ++mi) f.a[mo][mi] = ld4(Wm + ln.wo + 16 * mi);
+    f.bv[mo] = ld4(bias + 16 * mo + 4 * ln.g);
+  }
+  if (norm) load_norm(*norm, norm_w, ln);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// out^T[rt][mo] = W * in^T + bias
+template <int RT>
+DEV void wmul(const WFrag& f, const f32x4 (&in)[2][4], f32x4 (&out)[2][4]) {
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      f32x4 acc = bv;
+      f32x4 acc = f.bv[mo];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = mfma(a[mi][i], in[rt][mi][i], acc);
+        for (int i = 0; i < 4; ++i) acc = mfma(f.a[mo][mi][i], in[rt][mi][i], acc);
       out[rt][mo] = acc;
     }
   }
@@ -111,14 +216,8 @@ DEV void store_rows(float* buf, const Lane ln, const f32x4 (&v)[2][4], int nrows
 
 // torch.nn.LayerNorm(64), eps 1e-5, over the feature axis (in-lane 16 values + lane groups).
 template <int RT>
-DEV void layer_norm(f32x4 (&x)[2][4], const float* __restrict__ gamma,
-                    const float* __restrict__ beta, const Lane ln) {
-  f32x4 gm[4], bt[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    gm[m] = ld4(gamma + 16 * m + 4 * ln.g);
-    bt[m] = ld4(beta + 16 * m + 4 * ln.g);
-  }
+DEV void layer_norm(f32x4 (&x)[2][4], const NormParams& n, const Lane ln) {
+  if (ln.ablate & 16) return;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     float s = 0.f;
@@ -126,9 +225,7 @@ DEV void layer_norm(f32x4 (&x)[2][4], const float* __restrict__ gamma,
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) s += x[rt][m][i];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    const float mean = s * (1.0f / DM);
+    const float mean = group_sum(s) * (1.0f / DM);
     float q = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -137,15 +234,21 @@ DEV void layer_norm(f32x4 (&x)[2][4], const float* __restrict__ gamma,
         const float d = x[rt][m][i] - mean;
         q = fmaf(d, d, q);
       }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    const float inv = 1.0f / sqrtf(q * (1.0f / DM) + 1e-5f);
+    const float inv = 1.0f / sqrtf(group_sum(q) * (1.0f / DM) + 1e-5f);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        x[rt][m][i] = (x[rt][m][i] - mean) * inv * gm[m][i] + bt[m][i];
+        x[rt][m][i] = (x[rt][m][i] - mean) * inv * n.gm[m][i] + n.bt[m][i];
   }
+}
+template <int RT>
+DEV void layer_norm(f32x4 (&x)[2][4], const float* __restrict__ gamma,
+                    const float* __restrict__ beta, const Lane ln) {
+  (void)beta;  // stored right behind gamma
+  NormParams n;
+  load_norm(n, gamma, ln);
+  layer_norm<RT>(x, n, ln);
 }
 
 DEV float act(float v, int activation) {
@@ -179,99 +282,152 @@ DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const f32x4 (&
 
 // FullAttention (attn.py:18-36) on the Q/K/V rows in LDS; result in T layout (ctx).
 // RQ / RK: 16-row tiles of queries / keys. amap: this sample's [8][Lq][Lk] map or null.
+// Heads are processed NP pairs at a time, each step for all of them before the next step:
+// scores (MFMA), softmax (VALU, cross-lane), P*V (MFMA). The steps of different heads are
+// independent, so their latencies overlap instead of forming one long dependent chain.
 template <int RQ, int RK>
 DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, int Lk, bool causal,
                    const Lane ln, f32x4 (&ctx)[2][4], float* amap) {
+  constexpr int NP = (RQ * RK == 1) ? 4 : (RQ * RK == 2 ? 2 : 1);  // head pairs per group
   const float scale = 0.35355339059327373f;  // 1/sqrt(8), as float(1./sqrt(E))
   const bool upper = (ln.c & 8) != 0;        // lane feeds the second head of a pair
 #pragma unroll
-  for (int hp = 0; hp < 4; ++hp) {
-    f32x4 p[2][RK][RQ];  // [head of the pair][key tile][query tile]
+  for (int hp0 = 0; hp0 < 4; hp0 += NP) {
+    f32x4 p[NP][2][RK][RQ];  // [pair][head of the pair][key tile][query tile]
+    // ---- scores^T = K Q^T: lane (query 16*qt + c) holds keys 16*kt + 4*g + i ----
+    float2 kf[NP][2][RK], qf[NP][2][RQ];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int col = 8 * (2 * hp + hh) + 2 * ln.g;  // this lane's two head features
-      float2 kf[RK], qf[RQ];
+    for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-      for (int kt = 0; kt < RK; ++kt)
-        kf[kt] = *reinterpret_cast<const float2*>(Kb + (16 * kt + ln.c) * LDW + col);
+      for (int hh = 0; hh < 2; ++hh) {
+        const int col = 8 * (2 * (hp0 + pi) + hh) + 2 * ln.g;  // this lane's two head features
 #pragma unroll
-      for (int qt = 0; qt < RQ; ++qt)
-        qf[qt] = *reinterpret_cast<const float2*>(Qb + (16 * qt + ln.c) * LDW + col);
-      // scores^T: lane (query 16*qt + c) holds keys 16*kt + 4*g + i
+        for (int kt = 0; kt < RK; ++kt)
+          kf[pi][hh][kt] = *reinterpret_cast<const float2*>(Kb + (16 * kt + ln.c) * LDW + col);
 #pragma unroll
-      for (int kt = 0; kt < RK; ++kt)
+        for (int qt = 0; qt < RQ; ++qt)
+          qf[pi][hh][qt] = *reinterpret_cast<const float2*>(Qb + (16 * qt + ln.c) * LDW + col);
+      }
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < RQ; ++qt) {
+            f32x4 sc = zero4();
+            sc = mfma(kf[pi][hh][kt].x, qf[pi][hh][qt].x, sc);
+            sc = mfma(kf[pi][hh][kt].y, qf[pi][hh][qt].y, sc);
+            p[pi][hh][kt][qt] = sc;
+          }
+    // ---- masked, scaled softmax over the keys of each query ----
+    float mx[NP][2][RQ], sum[NP][2][RQ];
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
-          f32x4 s = zero4();
-          s = mfma(kf[kt].x, qf[qt].x, s);
-          s = mfma(kf[kt].y, qf[qt].y, s);
-          p[hh][kt][qt] = s;
-        }
-      // masked, scaled softmax over the keys of each query
-#pragma unroll
-      for (int qt = 0; qt < RQ; ++qt) {
-        const int query = 16 * qt + ln.c;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < RK; ++kt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int key = 16 * kt + 4 * ln.g + i;
-            const bool ok = key < Lk && (!causal || key <= query);
-            const float t = ok ? scale * p[hh][kt][qt][i] : -INFINITY;
-            p[hh][kt][qt][i] = t;
-            mx = fmaxf(mx, t);
-          }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < RK; ++kt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float e = expf(p[hh][kt][qt][i] - mx);
-            p[hh][kt][qt][i] = e;
-            sum += e;
-          }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-#pragma unroll
-        for (int kt = 0; kt < RK; ++kt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) p[hh][kt][qt][i] = p[hh][kt][qt][i] / sum;
-        if (amap && query < Lq) {
-          float* row = amap + ((size_t)(2 * hp + hh) * Lq + query) * Lk;
+          const int query = 16 * qt + ln.c;
+          float m = -INFINITY;
 #pragma unroll
           for (int kt = 0; kt < RK; ++kt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int key = 16 * kt + 4 * ln.g + i;
-              if (key < Lk) row[key] = p[hh][kt][qt][i];
+              const bool ok = key < Lk && (!causal || key <= query);
+              const float t = ok ? scale * p[pi][hh][kt][qt][i] : -INFINITY;
+              p[pi][hh][kt][qt][i] = t;
+              m = fmaxf(m, t);
             }
+          mx[pi][hh][qt] = m;
         }
-      }
-    }
-    // context^T tile (features 16*hp .. 16*hp+15): A = V^T with the other head's rows zeroed
-    f32x4 acc[RQ];
 #pragma unroll
-    for (int qt = 0; qt < RQ; ++qt) acc[qt] = zero4();
+    for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-    for (int kt = 0; kt < RK; ++kt)
+      for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int vr = 16 * kt + 4 * ln.g + i;
-        vr = vr < Lk ? vr : Lk - 1;  // padded keys carry probability 0; stay inside the region
-        const float v = Vb[vr * LDW + 16 * hp + ln.c];
-        const float v0 = upper ? 0.f : v;
-        const float v1 = upper ? v : 0.f;
+        for (int qt = 0; qt < RQ; ++qt) mx[pi][hh][qt] = group_max(mx[pi][hh][qt]);
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
-          acc[qt] = mfma(v0, p[0][kt][qt][i], acc[qt]);
-          acc[qt] = mfma(v1, p[1][kt][qt][i], acc[qt]);
-        }
-      }
+          float sm = 0.f;
 #pragma unroll
-    for (int qt = 0; qt < RQ; ++qt) ctx[qt][hp] = acc[qt];
+          for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float d = p[pi][hh][kt][qt][i] - mx[pi][hh][qt];
+              const float e = (ln.ablate & 4) ? d : __expf(d);
+              p[pi][hh][kt][qt][i] = e;
+              sm += e;
+            }
+          sum[pi][hh][qt] = sm;
+        }
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int qt = 0; qt < RQ; ++qt) sum[pi][hh][qt] = 1.0f / group_sum(sum[pi][hh][qt]);
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int qt = 0; qt < RQ; ++qt) {
+#pragma unroll
+          for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[pi][hh][kt][qt][i] *= sum[pi][hh][qt];
+          const int query = 16 * qt + ln.c;
+          if (amap && query < Lq) {
+            float* row = amap + ((size_t)(2 * (hp0 + pi) + hh) * Lq + query) * Lk;
+#pragma unroll
+            for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int key = 16 * kt + 4 * ln.g + i;
+                if (key < Lk) row[key] = p[pi][hh][kt][qt][i];
+              }
+          }
+        }
+    // ---- context^T tile (features 16*hp .. 16*hp+15): A = V^T with the other head's rows
+    // zeroed, so both heads of a pair accumulate into the same output tile ----
+    float vf[NP][RK][4];
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+      for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int vr = 16 * kt + 4 * ln.g + i;
+          vr = vr < Lk ? vr : Lk - 1;  // padded keys carry probability 0; stay inside the region
+          vf[pi][kt][i] = Vb[vr * LDW + 16 * (hp0 + pi) + ln.c];
+        }
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      f32x4 acc[RQ];
+#pragma unroll
+      for (int qt = 0; qt < RQ; ++qt) acc[qt] = zero4();
+#pragma unroll
+      for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v0 = upper ? 0.f : vf[pi][kt][i];
+          const float v1 = upper ? vf[pi][kt][i] : 0.f;
+#pragma unroll
+          for (int qt = 0; qt < RQ; ++qt) {
+            acc[qt] = mfma(v0, p[pi][0][kt][qt][i], acc[qt]);
+            acc[qt] = mfma(v1, p[pi][1][kt][qt][i], acc[qt]);
+          }
+        }
+#pragma unroll
+      for (int qt = 0; qt < RQ; ++qt) ctx[qt][hp0 + pi] = acc[qt];
+    }
   }
 }
 
@@ -279,76 +435,176 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
 constexpr int SZ_ATTN = 4 * (DM * DM + DM);
 constexpr int SZ_FFN = 2 * (DM * DM + DM);
 
-// AttentionLayer (attn.py:140-156): projections -> LDS, attention, output projection.
-// xq: query-side input, xkv: key/value-side input (T layout). Result in `o`.
-template <int RQ, int RK>
-DEV void attention_block(const float* __restrict__ w, float* smem, int R, const Lane ln,
-                         const f32x4 (&xq)[2][4], const f32x4 (&xkv)[2][4], int Lq, int Lk,
-                         bool causal, float* amap, f32x4 (&o)[2][4]) {
-  float* Qb = smem;  // R rows each; a padded tile read may run into the next region (finite data)
-  float* Kb = smem + R * LDW;
-  float* Vb = smem + 2 * R * LDW;
-  f32x4 t[2][4];
-  __syncthreads();  // earlier readers of the Q/K/V regions are done
-  linear64<RQ>(w, w + DM * DM, ln, xq, t);
-  store_rows<RQ>(Qb, ln, t, Lq);
-  linear64<RK>(w + (DM * DM + DM), w + (DM * DM + DM) + DM * DM, ln, xkv, t);
-  store_rows<RK>(Kb, ln, t, Lk);
-  linear64<RK>(w + 2 * (DM * DM + DM), w + 2 * (DM * DM + DM) + DM * DM, ln, xkv, t);
-  store_rows<RK>(Vb, ln, t, Lk);
-  __syncthreads();
-  f32x4 ctx[2][4];
-  attention<RQ, RK>(Qb, Kb, Vb, Lq, Lk, causal, ln, ctx, amap);
-  linear64<RQ>(w + 3 * (DM * DM + DM), w + 3 * (DM * DM + DM) + DM * DM, ln, ctx, o);
-}
+constexpr int SZ_LIN = DM * DM + DM;  // one Linear(64,64): weight | bias
+#ifndef CET_PIPE
+#define CET_PIPE 0
+#endif
 
-// conv1 -> activation -> conv2 of EncoderLayer / DecoderLayer (1x1 convolutions = Linear).
 template <int RT>
-DEV void ffn(const float* __restrict__ w, const Lane ln, int activation, const f32x4 (&x)[2][4],
-             f32x4 (&y)[2][4]) {
-  f32x4 h[2][4];
-  linear64<RT>(w, w + DM * DM, ln, x, h);
+DEV void activate(f32x4 (&h)[2][4], int activation) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) h[rt][m][i] = act(h[rt][m][i], activation);
-  linear64<RT>(w + DM * DM + DM, w + 2 * DM * DM + DM, ln, h, y);
 }
 
-// EncoderLayer.forward (encoder.py:37-53). Block: attn | ffn | norm1 g,b | norm2 g,b.
+// The layer functions below are written as explicit schedules over two weight-fragment
+// buffers A and B: while the MFMAs of one product run from one buffer, the fragments of the
+// next product are already on their way into the other. A layer pays the load latency once,
+// at its first two products.
+
+// Stores the three projections of an attention layer into the Q | K | V regions.
+// PIPE: the fragments of product n+1 are requested before the MFMAs of product n (two
+// buffers); otherwise one buffer is loaded and used in turn (half the registers).
+// On return with PIPE, B holds the fragments of the output projection.
+template <int RQ, int RK, bool PIPE>
+DEV void project_qkv(const float* __restrict__ w, float* smem, int R, const Lane ln,
+                     const f32x4 (&xq)[2][4], const f32x4 (&xkv)[2][4], int Lq, int Lk, WFrag& A,
+                     WFrag& B, bool a_loaded) {
+  float* Qb = smem;  // R rows each; a padded tile read may run into the next region (finite data)
+  float* Kb = smem + R * LDW;
+  float* Vb = smem + 2 * R * LDW;
+  f32x4 t[2][4];
+  __syncthreads();  // earlier readers of the Q/K/V regions are done
+  if (PIPE) {
+    if (!a_loaded) wload(A, w, ln);
+    wload(B, w + SZ_LIN, ln);
+    wmul<RQ>(A, xq, t);
+    store_rows<RQ>(Qb, ln, t, Lq);
+    wload(A, w + 2 * SZ_LIN, ln);
+    wmul<RK>(B, xkv, t);
+    store_rows<RK>(Kb, ln, t, Lk);
+    wload(B, w + 3 * SZ_LIN, ln);
+    wmul<RK>(A, xkv, t);
+    store_rows<RK>(Vb, ln, t, Lk);
+  } else {
+    wload(A, w, ln);
+    wmul<RQ>(A, xq, t);
+    store_rows<RQ>(Qb, ln, t, Lq);
+    wload(A, w + SZ_LIN, ln);
+    wmul<RK>(A, xkv, t);
+    store_rows<RK>(Kb, ln, t, Lk);
+    wload(A, w + 2 * SZ_LIN, ln);
+    wmul<RK>(A, xkv, t);
+    store_rows<RK>(Vb, ln, t, Lk);
+  }
+  __syncthreads();
+  PROF_MARK(ln, P_QKV);
+}
+
+// EncoderLayer.forward (encoder.py:37-53) with AttentionLayer / FullAttention (attn.py).
+// Block: q,k,v,o Linear | conv1 | conv2 | norm1 g,b | norm2 g,b.
 constexpr int SZ_ENC_LAYER = SZ_ATTN + SZ_FFN + 4 * DM;
 template <int RT>
 DEV void encoder_layer(const float* __restrict__ w, float* smem, int R, const Lane ln, int L,
                        int activation, float* amap, f32x4 (&x)[2][4]) {
-  f32x4 y[2][4];
-  attention_block<RT, RT>(w, smem, R, ln, x, x, L, L, false, amap, y);
-  add_into<RT>(x, y);
+  constexpr bool PIPE = CET_PIPE && RT == 1;
   const float* nw = w + SZ_ATTN + SZ_FFN;
-  layer_norm<RT>(x, nw, nw + DM, ln);
-  ffn<RT>(w + SZ_ATTN, ln, activation, x, y);
+  WFrag A, B;
+  NormParams n;
+  f32x4 t[2][4], y[2][4];
+  project_qkv<RT, RT, PIPE>(w, smem, R, ln, x, x, L, L, A, B, false);
+  attention<RT, RT>(smem, smem + R * LDW, smem + 2 * R * LDW, L, L, false, ln, y, amap);
+  PROF_MARK(ln, P_ATTN);
+  if (PIPE) {
+    wload(A, w + SZ_ATTN, ln, &n, nw);  // conv1, norm1
+    wmul<RT>(B, y, t);                  // output projection
+    PROF_MARK(ln, P_OPROJ);
+    wload(B, w + SZ_ATTN + SZ_LIN, ln);  // conv2
+    add_into<RT>(x, t);
+    layer_norm<RT>(x, n, ln);
+    load_norm(n, nw + 2 * DM, ln);  // norm2
+    __builtin_amdgcn_sched_barrier(0);
+    PROF_MARK(ln, P_ADDLN);
+    wmul<RT>(A, x, t);
+    activate<RT>(t, activation);
+    wmul<RT>(B, t, y);
+  } else {
+    wload(A, w + 3 * SZ_LIN, ln, &n, nw);
+    wmul<RT>(A, y, t);
+    PROF_MARK(ln, P_OPROJ);
+    add_into<RT>(x, t);
+    layer_norm<RT>(x, n, ln);
+    PROF_MARK(ln, P_ADDLN);
+    wload(A, w + SZ_ATTN, ln);
+    wmul<RT>(A, x, t);
+    activate<RT>(t, activation);
+    wload(A, w + SZ_ATTN + SZ_LIN, ln, &n, nw + 2 * DM);
+    wmul<RT>(A, t, y);
+  }
+  PROF_MARK(ln, P_FFN);
   add_into<RT>(x, y);
-  layer_norm<RT>(x, nw + 2 * DM, nw + 3 * DM, ln);
+  layer_norm<RT>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
 }
 
 // DecoderLayer.forward (decoder.py:20-36).
-// Block: self attn | cross attn | ffn | norm1 | norm2 | norm3.
+// Block: self q,k,v,o | cross q,k,v,o | conv1 | conv2 | norm1 | norm2 | norm3.
 constexpr int SZ_DEC_LAYER = 2 * SZ_ATTN + SZ_FFN + 6 * DM;
 template <int RD, int RM>
 DEV void decoder_layer(const float* __restrict__ w, float* smem, int R, const Lane ln, int Ld,
                        int Lm, int activation, const f32x4 (&mem)[2][4], f32x4 (&x)[2][4]) {
-  f32x4 y[2][4];
-  const float* nw = w + 2 * SZ_ATTN + SZ_FFN;
-  attention_block<RD, RD>(w, smem, R, ln, x, x, Ld, Ld, true, nullptr, y);
+  constexpr bool PIPE = CET_PIPE && RD == 1 && RM == 1;
+  float* Qb = smem;
+  float* Kb = smem + R * LDW;
+  float* Vb = smem + 2 * R * LDW;
+  const float* wc = w + SZ_ATTN;       // cross attention
+  const float* wf = w + 2 * SZ_ATTN;   // conv1 | conv2
+  const float* nw = wf + SZ_FFN;
+  WFrag A, B;
+  NormParams n;
+  f32x4 t[2][4], y[2][4];
+  // causal self attention
+  project_qkv<RD, RD, PIPE>(w, smem, R, ln, x, x, Ld, Ld, A, B, false);
+  attention<RD, RD>(Qb, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
+  PROF_MARK(ln, P_ATTN);
+  if (PIPE) {
+    wload(A, wc, ln, &n, nw);  // cross q, norm1
+    wmul<RD>(B, y, t);
+  } else {
+    wload(A, w + 3 * SZ_LIN, ln, &n, nw);
+    wmul<RD>(A, y, t);
+  }
+  PROF_MARK(ln, P_OPROJ);
+  add_into<RD>(x, t);
+  layer_norm<RD>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+  // cross attention: queries from x, keys / values from the encoder memory
+  project_qkv<RD, RM, PIPE>(wc, smem, R, ln, x, mem, Ld, Lm, A, B, PIPE);
+  attention<RD, RM>(Qb, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
+  PROF_MARK(ln, P_ATTN);
+  if (PIPE) {
+    wload(A, wf, ln, &n, nw + 2 * DM);  // conv1, norm2
+    wmul<RD>(B, y, t);
+    PROF_MARK(ln, P_OPROJ);
+    wload(B, wf + SZ_LIN, ln);  // conv2
+    add_into<RD>(x, t);
+    layer_norm<RD>(x, n, ln);
+    load_norm(n, nw + 4 * DM, ln);  // norm3
+    __builtin_amdgcn_sched_barrier(0);
+    PROF_MARK(ln, P_ADDLN);
+    wmul<RD>(A, x, t);
+    activate<RD>(t, activation);
+    wmul<RD>(B, t, y);
+  } else {
+    wload(A, wc + 3 * SZ_LIN, ln, &n, nw + 2 * DM);
+    wmul<RD>(A, y, t);
+    PROF_MARK(ln, P_OPROJ);
+    add_into<RD>(x, t);
+    layer_norm<RD>(x, n, ln);
+    PROF_MARK(ln, P_ADDLN);
+    wload(A, wf, ln);
+    wmul<RD>(A, x, t);
+    activate<RD>(t, activation);
+    wload(A, wf + SZ_LIN, ln, &n, nw + 4 * DM);
+    wmul<RD>(A, t, y);
+  }
+  PROF_MARK(ln, P_FFN);
   add_into<RD>(x, y);
-  layer_norm<RD>(x, nw, nw + DM, ln);
-  attention_block<RD, RM>(w + SZ_ATTN, smem, R, ln, x, mem, Ld, Lm, false, nullptr, y);
-  add_into<RD>(x, y);
-  layer_norm<RD>(x, nw + 2 * DM, nw + 3 * DM, ln);
-  ffn<RD>(w + 2 * SZ_ATTN, ln, activation, x, y);
-  add_into<RD>(x, y);
-  layer_norm<RD>(x, nw + 4 * DM, nw + 5 * DM, ln);
+  layer_norm<RD>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
 }
 
 // ConvLayer.forward (encoder.py:17-23): Conv1d(64->64, k=3, circular pad 2) -> BatchNorm1d
@@ -365,6 +621,23 @@ DEV int distil(const float* __restrict__ w, float* smem, int R, const Lane ln, i
   __syncthreads();
   const int Lc = L + 2;
   f32x4 y[2][4];
+  // Weight fragments of one 16-feature output block (3 taps x 4 k-blocks) plus its bias and
+  // folded BatchNorm vectors; requested one block ahead of the MFMAs that use them.
+  struct Block {
+    f32x4 a[3][4], bias, al, be;
+  };
+  auto load_block = [&](Block& blk, int mo) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* Wm = w + (j * DM + 16 * mo) * DM;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) blk.a[j][mi] = ld4(Wm + ln.wo + 16 * mi);
+    }
+    blk.bias = ld4(w + 3 * DM * DM + 16 * mo + 4 * ln.g);
+    blk.al = ld4(w + 3 * DM * DM + DM + 16 * mo + 4 * ln.g);
+    blk.be = ld4(w + 3 * DM * DM + 2 * DM + 16 * mo + 4 * ln.g);
+    __builtin_amdgcn_sched_barrier(0);
+  };
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     int t = 16 * rt + ln.c;
@@ -378,26 +651,30 @@ DEV int distil(const float* __restrict__ w, float* smem, int R, const Lane ln, i
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) bf[j][mi] = ld4(Xb + src * LDW + 16 * mi + 4 * ln.g);
     }
-#pragma unroll
-    for (int mo = 0; mo < 4; ++mo) {
-      f32x4 acc = ld4(w + 3 * DM * DM + 16 * mo + 4 * ln.g);  // bias
+    auto compute = [&](const Block& blk, int mo) {
+      f32x4 acc = blk.bias;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const f32x4 a = ld4(w + (j * DM + 16 * mo + ln.c) * DM + 16 * mi + 4 * ln.g);
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc = mfma(a[i], bf[j][mi][i], acc);
-        }
-      const f32x4 al = ld4(w + 3 * DM * DM + DM + 16 * mo + 4 * ln.g);
-      const f32x4 be = ld4(w + 3 * DM * DM + 2 * DM + 16 * mo + 4 * ln.g);
+          for (int i = 0; i < 4; ++i) acc = mfma(blk.a[j][mi][i], bf[j][mi][i], acc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float v = acc[i] * al[i] + be[i];
-        acc[i] = v > 0.f ? v : (expf(v) - 1.0f);
+        const float v = acc[i] * blk.al[i] + blk.be[i];
+        acc[i] = v > 0.f ? v : (__expf(v) - 1.0f);
       }
       y[rt][mo] = acc;
-    }
+    };
+    Block b0, b1;
+    load_block(b0, 0);
+    load_block(b1, 1);
+    compute(b0, 0);
+    load_block(b0, 2);
+    compute(b1, 1);
+    load_block(b1, 3);
+    compute(b0, 2);
+    compute(b1, 3);
   }
   store_rows<RT>(Yb, ln, y, Lc);
   __syncthreads();
@@ -437,11 +714,26 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
   __syncthreads();
   const float* bias = w + 3 * DM * CIN;
   const float* pe = bias + DM;
+  // all weight fragments (3 taps x NKB k-blocks x 4 output blocks) are requested up front
+  f32x4 a[4][3][NKB], bv[4];
+  const unsigned wo = ln.c * CIN + 4 * ln.g;
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* Wm = w + (j * DM + 16 * mo) * CIN;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) a[mo][j][kb] = ld4(Wm + wo + 16 * kb);
+    }
+    bv[mo] = ld4(bias + 16 * mo + 4 * ln.g);
+  }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     int t = 16 * rt + ln.c;
     t = t < L ? t : L - 1;
-    f32x4 bf[3][NKB];
+    f32x4 bf[3][NKB], pv[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) pv[mo] = ld4(pe + t * DM + 16 * mo + 4 * ln.g);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       int src = t + j - 1;
@@ -456,13 +748,11 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          const f32x4 a = ld4(w + (j * DM + 16 * mo + ln.c) * CIN + 16 * kb + 4 * ln.g);
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc = mfma(a[i], bf[j][kb][i], acc);
-        }
-      acc += ld4(bias + 16 * mo + 4 * ln.g);
-      acc += ld4(pe + t * DM + 16 * mo + 4 * ln.g);
+          for (int i = 0; i < 4; ++i) acc = mfma(a[mo][j][kb][i], bf[j][kb][i], acc);
+      acc += bv[mo];
+      acc += pv[mo];
       x[rt][mo] = acc;
     }
   }
@@ -470,14 +760,15 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
 
 // Rows [first, first+n) of x (via LDS) -> rows [dst, dst+n) of `into`; other rows of `into`
 // keep their value. Used for x[:, -inp_len:, :] and for the concatenation of the encoder
-// outputs (encoder.py:96-99).
+// outputs (encoder.py:96-99). RS / RD: tiles of the source / destination that can be involved.
+template <int RS, int RD>
 DEV void move_rows(float* smem, const Lane ln, const f32x4 (&x)[2][4], int first, int n, int dst,
                    f32x4 (&into)[2][4]) {
   __syncthreads();
-  store_rows<2>(smem, ln, x, first + n);
+  store_rows<RS>(smem, ln, x, first + n);
   __syncthreads();
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RD; ++rt) {
     const int r = 16 * rt + ln.c;
     if (r >= dst && r < dst + n) {
 #pragma unroll
@@ -487,21 +778,71 @@ DEV void move_rows(float* smem, const Lane ln, const f32x4 (&x)[2][4], int first
   }
 }
 
-// WPE: waves per SIMD the register allocation must allow (occupancy is then set by LDS).
-template <int WPE>
-__global__ __launch_bounds__(64, WPE) void informer_kernel(const KArgs a) {
+// State that the steps of the encoder stack advance.
+struct Cursor {
+  const float* w;  // next weight block
+  float* attn;     // next attention map block (null: not wanted)
+  float* taps;     // next debug stage (null: not wanted)
+};
+
+// One encoder step on RT row tiles (RM: tiles of the memory).
+template <int RT, int RM>
+DEV void run_op(const Op op, const KArgs& a, Cursor& cu, float* smem, int R, const Lane ln, int b,
+                f32x4 (&x)[2][4], f32x4 (&mem)[2][4]) {
+  const int L = op.L;
+  if (op.type == OP_LAYER) {
+    float* amap = nullptr;
+    if (cu.attn) {
+      amap = cu.attn + (size_t)b * NHEAD * L * L;
+      cu.attn += (size_t)a.B * NHEAD * L * L;
+    }
+    encoder_layer<RT>(cu.w, smem, R, ln, L, a.activation, amap, x);
+    if (!(a.ablate & 8)) cu.w += SZ_ENC_LAYER;
+    tap<RT>(cu.taps, a.B, b, L, ln, x);
+  } else if (op.type == OP_DISTIL) {
+    const int Lo = distil<RT>(cu.w, smem, R, ln, L, x);
+    cu.w += SZ_DISTIL;
+    tap<RT>(cu.taps, a.B, b, Lo, ln, x);
+    PROF_MARK(ln, P_DISTIL);
+  } else if (op.type == OP_NORM_APPEND) {
+    layer_norm<RT>(x, cu.w, cu.w + DM, ln);
+    cu.w += 2 * DM;
+    tap<RT>(cu.taps, a.B, b, L, ln, x);
+    PROF_MARK(ln, P_ADDLN);
+    move_rows<RT, RM>(smem, ln, x, 0, L, op.a, mem);
+    PROF_MARK(ln, P_MOVE);
+  } else {
+    move_rows<RT, RT>(smem, ln, x, op.a, op.b, 0, x);
+    PROF_MARK(ln, P_MOVE);
+  }
+}
+
+// One wave = one sequence. RD / RM: row tiles of the decoder sequence / of the encoder memory
+// (known on the host). The encoder steps that touch more than 16 rows come first (sequence
+// lengths only shrink along the stack) and run on two row tiles; everything after them runs
+// on one, so the second tile's registers are free for weight prefetching there.
+template <int RD, int RM>
+__global__ __launch_bounds__(64, 2) void informer_kernel(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x;
-  const Lane ln{lane & 15, lane >> 4};
-  const int b = blockIdx.x;
+#ifdef CET_PROF
+  int prof_idx = 0;
+  const int prof_stride = a.B >= PROF_SAMPLES ? a.B / PROF_SAMPLES : 1;
+  const int prof_slot = (int)blockIdx.x / prof_stride;
+  const bool prof_on = (int)blockIdx.x % prof_stride == 0 && prof_slot < PROF_SAMPLES;
+  const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)),
+                prof_on ? a.prof + (size_t)prof_slot * PROF_MAXM : nullptr, &prof_idx};
+  PROF_MARK(ln, P_OTHER);
+#else
+  const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4))};
+#endif
   const int R = a.region_rows;
+  const int b = blockIdx.x;
 
   // Rows the padded 16-row tiles may touch must hold finite numbers from the start.
   for (int i = lane; i < 3 * R * LDW / 4; i += 64) st4(smem + 4 * i, zero4());
 
-  const float* w = a.w;
-  float* taps = a.taps;
-  float* attn = a.attn;
+  Cursor cu{a.w, a.attn, a.taps};
   f32x4 x[2][4], mem[2][4];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -509,77 +850,52 @@ __global__ __launch_bounds__(64, WPE) void informer_kernel(const KArgs a) {
     for (int m = 0; m < 4; ++m) x[rt][m] = mem[rt][m] = zero4();
 
   // ---- encoder embedding ------------------------------------------------------------
-  int L = a.seq_len;
   {
+    const int L = a.seq_len;
     const float* xg = a.x_enc + (size_t)b * L * a.enc_in;
-    if (a.enc_in == 16) embed<2, 1>(w, xg, smem, ln, lane, L, x);
-    else embed<2, 2>(w, xg, smem, ln, lane, L, x);
-    w += 3 * DM * a.enc_in + DM + L * DM;
-    tap<2>(taps, a.B, b, L, ln, x);
+    if (L > 16) {
+      if (a.enc_in == 16) embed<2, 1>(cu.w, xg, smem, ln, lane, L, x);
+      else embed<2, 2>(cu.w, xg, smem, ln, lane, L, x);
+      tap<2>(cu.taps, a.B, b, L, ln, x);
+    } else {
+      if (a.enc_in == 16) embed<1, 1>(cu.w, xg, smem, ln, lane, L, x);
+      else embed<1, 2>(cu.w, xg, smem, ln, lane, L, x);
+      tap<1>(cu.taps, a.B, b, L, ln, x);
+    }
+    cu.w += 3 * DM * a.enc_in + DM + L * DM;
+    PROF_MARK(ln, P_EMBED);
   }
-  const float* w_dec_emb = w;
+  const float* w_dec_emb = cu.w;
   const int Ld = a.label_len + a.pred_len;
-  w += 3 * DM * a.dec_in + DM + Ld * DM;
+  cu.w += 3 * DM * a.dec_in + DM + Ld * DM;
 
   // ---- encoder stack (encoder.py:87-101) ---------------------------------------------
-  int cur = L, inp_len = L, mem_rows = 0;
-  for (int e = 0; e < a.n_enc; ++e) {
-    const int el = a.enc_layers[e];
-    const int take = inp_len < cur ? inp_len : cur;
-    if (take < cur) move_rows(smem, ln, x, cur - take, take, 0, x);
-    L = take;
-    for (int l = 0; l < el; ++l) {
-      float* amap = nullptr;
-      if (attn) {
-        amap = attn + (size_t)b * NHEAD * L * L;
-        attn += (size_t)a.B * NHEAD * L * L;
-      }
-      if (L > 16) encoder_layer<2>(w, smem, R, ln, L, a.activation, amap, x);
-      else encoder_layer<1>(w, smem, R, ln, L, a.activation, amap, x);
-      w += SZ_ENC_LAYER;
-      tap<2>(taps, a.B, b, L, ln, x);
-      if (a.distil && l < el - 1) {
-        if (L + 2 > 16) L = distil<2>(w, smem, R, ln, L, x);
-        else L = distil<1>(w, smem, R, ln, L, x);
-        w += SZ_DISTIL;
-        tap<2>(taps, a.B, b, L, ln, x);
-      }
-    }
-    if (L > 16) layer_norm<2>(x, w, w + DM, ln);
-    else layer_norm<1>(x, w, w + DM, ln);
-    w += 2 * DM;
-    tap<2>(taps, a.B, b, L, ln, x);
-    move_rows(smem, ln, x, 0, L, mem_rows, mem);
-    mem_rows += L;
-    cur = L;
-    inp_len /= 2;
-  }
-  tap<2>(taps, a.B, b, mem_rows, ln, mem);
+  int i = 0;
+  for (; i < a.n_ops2; ++i) run_op<2, RM>(a.ops[i], a, cu, smem, R, ln, b, x, mem);
+  for (; i < a.n_ops; ++i) run_op<1, RM>(a.ops[i], a, cu, smem, R, ln, b, x, mem);
+  tap<RM>(cu.taps, a.B, b, a.mem_rows, ln, mem);
 
   // ---- decoder ---------------------------------------------------------------------
   {
     const float* xg = a.x_dec + (size_t)b * Ld * a.dec_in;
-    if (a.dec_in == 16) embed<2, 1>(w_dec_emb, xg, smem, ln, lane, Ld, x);
-    else embed<2, 2>(w_dec_emb, xg, smem, ln, lane, Ld, x);
-    tap<2>(taps, a.B, b, Ld, ln, x);
+    if (a.dec_in == 16) embed<RD, 1>(w_dec_emb, xg, smem, ln, lane, Ld, x);
+    else embed<RD, 2>(w_dec_emb, xg, smem, ln, lane, Ld, x);
+    tap<RD>(cu.taps, a.B, b, Ld, ln, x);
+    PROF_MARK(ln, P_EMBED);
   }
   for (int l = 0; l < a.d_layers; ++l) {
-    if (Ld > 16) {
-      if (mem_rows > 16) decoder_layer<2, 2>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
-      else decoder_layer<2, 1>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
-    } else {
-      if (mem_rows > 16) decoder_layer<1, 2>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
-      else decoder_layer<1, 1>(w, smem, R, ln, Ld, mem_rows, a.activation, mem, x);
-    }
-    w += SZ_DEC_LAYER;
-    tap<2>(taps, a.B, b, Ld, ln, x);
+    decoder_layer<RD, RM>(cu.w, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
+    if (!(a.ablate & 8)) cu.w += SZ_DEC_LAYER;
+    tap<RD>(cu.taps, a.B, b, Ld, ln, x);
   }
-  layer_norm<2>(x, w, w + DM, ln);
-  w += 2 * DM;
-  tap<2>(taps, a.B, b, Ld, ln, x);
+  layer_norm<RD>(x, cu.w, cu.w + DM, ln);
+  cu.w += 2 * DM;
+  tap<RD>(cu.taps, a.B, b, Ld, ln, x);
 
   // ---- projection Linear(64 -> c_out) and the last pred_len rows ------------------------
   // Block: W[ceil16(c_out)][64] zero padded | bias[ceil16(c_out)].
+  PROF_MARK(ln, P_ADDLN);
+  const float* w = cu.w;
   const int n_mo = (a.c_out + 15) / 16;
   const float* pb = w + n_mo * 16 * DM;
   for (int mo = 0; mo < n_mo; ++mo) {
@@ -588,18 +904,19 @@ __global__ __launch_bounds__(64, WPE) void informer_kernel(const KArgs a) {
     for (int mi = 0; mi < 4; ++mi) wa[mi] = ld4(w + (16 * mo + ln.c) * DM + 16 * mi + 4 * ln.g);
     const f32x4 bv = ld4(pb + 16 * mo + 4 * ln.g);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RD; ++rt) {
       f32x4 acc = bv;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = mfma(wa[mi][i], x[rt][mi][i], acc);
+        for (int i2 = 0; i2 < 4; ++i2) acc = mfma(wa[mi][i2], x[rt][mi][i2], acc);
       const int r = 16 * rt + ln.c;
       const int f0 = 16 * mo + 4 * ln.g;
       if (r >= Ld - a.pred_len && r < Ld && f0 < a.c_out)
         st4(a.out + ((size_t)b * a.pred_len + (r - (Ld - a.pred_len))) * a.c_out + f0, acc);
     }
   }
+  PROF_MARK(ln, P_PROJ);
 }
 
 }  // namespace
@@ -791,23 +1108,88 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   a.n_enc = m->d.n_enc; a.distil = m->d.distil; a.activation = m->d.activation;
   a.d_layers = m->d.d_layers;
   for (int i = 0; i < 8; ++i) a.enc_layers[i] = m->d.enc_layers[i];
+  // Steps of the encoder stack (encoder.py:87-101).
+  {
+    int n = 0, cur = m->d.seq_len, inp_len = m->d.seq_len, mem_rows = 0, n2 = 0;
+    auto push = [&](int type, int L, int p, int q, int need) {
+      a.ops[n] = Op{(unsigned char)type, (unsigned char)L, (unsigned char)p, (unsigned char)q};
+      if (need > 16) n2 = n + 1;
+      ++n;
+    };
+    for (int e = 0; e < m->d.n_enc; ++e) {
+      const int el = m->d.enc_layers[e];
+      const int take = inp_len < cur ? inp_len : cur;
+      if (take < cur) push(OP_SLICE, cur, cur - take, take, cur);
+      int L = take;
+      for (int l = 0; l < el; ++l) {
+        push(OP_LAYER, L, 0, 0, L);
+        if (m->d.distil && l < el - 1) {
+          push(OP_DISTIL, L, 0, 0, L + 2);
+          L = (L + 1) / 2 + 1;
+        }
+      }
+      push(OP_NORM_APPEND, L, mem_rows, 0, L);
+      mem_rows += L;
+      cur = L;
+      inp_len /= 2;
+    }
+    a.n_ops = n;
+    a.n_ops2 = n2;
+    a.mem_rows = mem_rows;
+  }
   // LDS: three regions of R rows (Q | K | V; also the conv / max-pool staging, which needs
-  // L + (L + 2) rows, and the 32-row staging of move_rows).
+  // L + (L + 2) rows, and the staging of move_rows).
   const int Ld = m->d.label_len + m->d.pred_len;
   int R = m->d.seq_len > Ld ? m->d.seq_len : Ld;
   if (R < m->d.mem_rows) R = m->d.mem_rows;
   if (R < 12) R = 12;
   a.region_rows = R;
   const size_t lds = (size_t)3 * R * LDW * sizeof(float);
-  static const int wpe = [] {
-    const char* e = getenv("CET_INFORMER_WPE");
-    return e ? atoi(e) : 2;
+  static const int ablate = [] {
+    const char* e = getenv("CET_INFORMER_ABLATE");
+    return e ? atoi(e) : 0;
   }();
-  if (wpe == 1)
-    hipLaunchKernelGGL(informer_kernel<1>, dim3((unsigned)B), dim3(64), lds, stream, a);
-  else
-    hipLaunchKernelGGL(informer_kernel<2>, dim3((unsigned)B), dim3(64), lds, stream, a);
+  a.ablate = ablate;
+#ifdef CET_PROF
+  static unsigned long long* prof_dev = nullptr;
+  const size_t prof_bytes = (size_t)PROF_SAMPLES * PROF_MAXM * sizeof(unsigned long long);
+  if (!prof_dev) CET_HIP(hipMalloc(&prof_dev, prof_bytes));
+  CET_HIP(hipMemsetAsync(prof_dev, 0, prof_bytes, stream));
+  a.prof = prof_dev;
+#endif
+  const bool d2 = Ld > 16, m2 = a.mem_rows > 16;
+  const dim3 grid((unsigned)B), block(64);
+  if (!d2 && !m2) hipLaunchKernelGGL((informer_kernel<1, 1>), grid, block, lds, stream, a);
+  else if (!d2 && m2) hipLaunchKernelGGL((informer_kernel<1, 2>), grid, block, lds, stream, a);
+  else if (d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 1>), grid, block, lds, stream, a);
+  else hipLaunchKernelGGL((informer_kernel<2, 2>), grid, block, lds, stream, a);
   CET_HIP(hipGetLastError());
+#ifdef CET_PROF
+  {
+    static unsigned long long h[PROF_SAMPLES * PROF_MAXM];
+    CET_HIP(hipStreamSynchronize(stream));
+    CET_HIP(hipMemcpy(h, prof_dev, sizeof h, hipMemcpyDeviceToHost));
+    static const char* names[P_N] = {"embed", "qkv", "attn", "oproj", "add+ln", "ffn", "distil",
+                                     "move", "proj", "other"};
+    double sum[P_N] = {0}, tot = 0, t0min = 0, t1max = 0;
+    int waves = 0;
+    for (int s = 0; s < PROF_SAMPLES; ++s) {
+      const unsigned long long* t = h + (size_t)s * PROF_MAXM;
+      if (!t[0]) continue;
+      ++waves;
+      int n = 1;
+      for (; n < PROF_MAXM && t[n]; ++n) sum[t[n] & 15] += (double)((t[n] >> 4) - (t[n - 1] >> 4));
+      tot += (double)((t[n - 1] >> 4) - (t[0] >> 4));
+      if (waves == 1 || (double)(t[0] >> 4) < t0min) t0min = (double)(t[0] >> 4);
+      if ((double)(t[n - 1] >> 4) > t1max) t1max = (double)(t[n - 1] >> 4);
+    }
+    if (waves) {
+      fprintf(stderr, "[cet prof] %d sampled waves, clocks per wave:", waves);
+      for (int i = 0; i < P_N; ++i) fprintf(stderr, " %s=%.0f", names[i], sum[i] / waves);
+      fprintf(stderr, " total=%.0f span=%.0f\n", tot / waves, t1max - t0min);
+    }
+  }
+#endif
   return CET_OK;
 }
 
