@@ -18,7 +18,8 @@
 // cross-lane steps. The normalised probabilities are then the B operand of the P*V product
 // as they stand; two heads share one 16-feature output tile by zeroing the other head's
 // rows of the V^T operand.
-// All arithmetic is fp32 (MFMA f32 = exact fmaf chains); exp/erf/sqrt are the accurate forms.
+// All arithmetic is fp32 (MFMA f32 = exact fmaf chains). exp is 2^(x log2 e) on the hardware
+// exp2 (1 ulp), reciprocals and 1/sqrt are the 1-ulp hardware forms, erf is a 1.5e-7 fit.
 #include <cstdio>
 #include <cstdlib>
 #include <new>
@@ -83,6 +84,18 @@ DEV f32x4 mfma(float a, float b, f32x4 c) {
 DEV f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// Pins a wave-uniform pointer in scalar registers: loads through it then take the
+// "scalar base + per-lane 32-bit offset" addressing form and need no 64-bit vector adds.
+// The result is typed as a global-memory pointer (the laundering would otherwise demote
+// the loads to flat ones).
+typedef const __attribute__((address_space(1))) float* gptr;
+DEV gptr uniform(const float* p) {
+  asm("" : "+s"(p));
+  return (gptr)p;
+}
+DEV f32x4 ld4(gptr p) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(p);
+}
 
 // Sum / max over the four lane groups g (lanes c, c+16, c+32, c+48), result in all four.
 // v_permlane16_swap / v_permlane32_swap exchange 16- and 32-lane halves inside the VALU, so
@@ -156,7 +169,8 @@ enum { P_EMBED = 0, P_QKV, P_ATTN, P_OPROJ, P_ADDLN, P_FFN, P_DISTIL, P_MOVE, P_
 struct NormParams {
   f32x4 gm[4], bt[4];  // gamma / beta of this lane's 16 features
 };
-DEV void load_norm(NormParams& n, const float* __restrict__ gamma_beta, const Lane ln) {
+DEV void load_norm(NormParams& n, const float* __restrict__ gamma_beta_, const Lane ln) {
+  const gptr gamma_beta = uniform(gamma_beta_);
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     n.gm[m] = ld4(gamma_beta + 16 * m + 4 * ln.g);
@@ -173,10 +187,10 @@ struct WFrag {
 // of their use, which the register-bound compiler would otherwise undo.
 DEV void wload(WFrag& f, const float* __restrict__ W, const Lane ln, NormParams* norm = nullptr,
                const float* __restrict__ norm_w = nullptr) {
-  const float* bias = W + DM * DM;
+  const gptr bias = uniform(W + DM * DM);
 #pragma unroll
   for (int mo = 0; mo < 4; ++mo) {
-    const float* Wm = W + 16 * mo * DM;
+    const gptr Wm = uniform(W + 16 * mo * DM);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) f.a[mo][mi] = ld4(Wm + ln.wo + 16 * mi);
     f.bv[mo] = ld4(bias + 16 * mo + 4 * ln.g);
@@ -234,7 +248,7 @@ DEV void layer_norm(f32x4 (&x)[2][4], const NormParams& n, const Lane ln) {
         const float d = x[rt][m][i] - mean;
         q = fmaf(d, d, q);
       }
-    const float inv = 1.0f / sqrtf(group_sum(q) * (1.0f / DM) + 1e-5f);
+    const float inv = __builtin_amdgcn_rsqf(group_sum(q) * (1.0f / DM) + 1e-5f);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -251,9 +265,21 @@ DEV void layer_norm(f32x4 (&x)[2][4], const float* __restrict__ gamma,
   layer_norm<RT>(x, n, ln);
 }
 
+// relu, or gelu(v) = v * Phi(v) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7):
+// 1 - erf(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z), z >= 0.
+// Written as max(v, 0) - |v| / 2 * (1 - erf(|v| / sqrt 2)), which is branch-free and has no
+// cancellation in the negative tail.
 DEV float act(float v, int activation) {
-  if (activation == 0) return v > 0.f ? v : 0.f;
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pos = fmaxf(v, 0.f);
+  if (activation == 0) return pos;
+  const float av = fabsf(v);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, av, 1.0f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(av * av * (-0.5f * 1.44269504088896340736f));
+  return fmaf(-0.5f * av, q * t * e, pos);
 }
 
 template <int RT>
@@ -372,7 +398,8 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int qt = 0; qt < RQ; ++qt) sum[pi][hh][qt] = 1.0f / group_sum(sum[pi][hh][qt]);
+        for (int qt = 0; qt < RQ; ++qt)
+          sum[pi][hh][qt] = __builtin_amdgcn_rcpf(group_sum(sum[pi][hh][qt]));
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
@@ -629,13 +656,14 @@ DEV int distil(const float* __restrict__ w, float* smem, int R, const Lane ln, i
   auto load_block = [&](Block& blk, int mo) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float* Wm = w + (j * DM + 16 * mo) * DM;
+      const gptr Wm = uniform(w + (j * DM + 16 * mo) * DM);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) blk.a[j][mi] = ld4(Wm + ln.wo + 16 * mi);
     }
-    blk.bias = ld4(w + 3 * DM * DM + 16 * mo + 4 * ln.g);
-    blk.al = ld4(w + 3 * DM * DM + DM + 16 * mo + 4 * ln.g);
-    blk.be = ld4(w + 3 * DM * DM + 2 * DM + 16 * mo + 4 * ln.g);
+    const gptr vec = uniform(w + 3 * DM * DM + 16 * mo);
+    blk.bias = ld4(vec + 4 * ln.g);
+    blk.al = ld4(vec + DM + 4 * ln.g);
+    blk.be = ld4(vec + 2 * DM + 4 * ln.g);
     __builtin_amdgcn_sched_barrier(0);
   };
 #pragma unroll
@@ -721,11 +749,11 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
   for (int mo = 0; mo < 4; ++mo) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float* Wm = w + (j * DM + 16 * mo) * CIN;
+      const gptr Wm = uniform(w + (j * DM + 16 * mo) * CIN);
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) a[mo][j][kb] = ld4(Wm + wo + 16 * kb);
     }
-    bv[mo] = ld4(bias + 16 * mo + 4 * ln.g);
+    bv[mo] = ld4(uniform(bias + 16 * mo) + 4 * ln.g);
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
