@@ -82,6 +82,7 @@ DEV f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 DEV f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+DEV f32x4 splat(float v) { return f32x4{v, v, v, v}; }
 DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // Pins a wave-uniform pointer in scalar registers: loads through it then take the
@@ -234,26 +235,23 @@ DEV void layer_norm(f32x4 (&x)[2][4], const NormParams& n, const Lane ln) {
   if (ln.ablate & 16) return;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    float s = 0.f;
+    // sums are kept four wide (packed fp32 adds / FMAs) and folded at the end
+    const f32x4 s4 = (x[rt][0] + x[rt][1]) + (x[rt][2] + x[rt][3]);
+    const float mean = group_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / DM);
+    f32x4 q4 = zero4();
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 d = x[rt][m] - mean;
+      q4 = __builtin_elementwise_fma(d, d, q4);
+    }
+    const float var = group_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / DM);
+    const float inv = __builtin_amdgcn_rsqf(var + 1e-5f);
+    const float shift = -mean * inv;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s += x[rt][m][i];
-    const float mean = group_sum(s) * (1.0f / DM);
-    float q = 0.f;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float d = x[rt][m][i] - mean;
-        q = fmaf(d, d, q);
-      }
-    const float inv = __builtin_amdgcn_rsqf(group_sum(q) * (1.0f / DM) + 1e-5f);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        x[rt][m][i] = (x[rt][m][i] - mean) * inv * n.gm[m][i] + n.bt[m][i];
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 xn = x[rt][m] * inv + shift;  // (x - mean) / sqrt(var + eps)
+      x[rt][m] = __builtin_elementwise_fma(xn, n.gm[m], n.bt[m]);
+    }
   }
 }
 template <int RT>
@@ -269,17 +267,22 @@ DEV void layer_norm(f32x4 (&x)[2][4], const float* __restrict__ gamma,
 // 1 - erf(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z), z >= 0.
 // Written as max(v, 0) - |v| / 2 * (1 - erf(|v| / sqrt 2)), which is branch-free and has no
 // cancellation in the negative tail.
-DEV float act(float v, int activation) {
-  const float pos = fmaxf(v, 0.f);
+DEV f32x4 act(f32x4 v, int activation) {
+  const f32x4 pos = __builtin_elementwise_max(v, zero4());
   if (activation == 0) return pos;
-  const float av = fabsf(v);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, av, 1.0f));
-  float q = fmaf(1.061405429f, t, -1.453152027f);
-  q = fmaf(q, t, 1.421413741f);
-  q = fmaf(q, t, -0.284496736f);
-  q = fmaf(q, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(av * av * (-0.5f * 1.44269504088896340736f));
-  return fmaf(-0.5f * av, q * t * e, pos);
+  const f32x4 av = __builtin_elementwise_abs(v);
+  const f32x4 d = __builtin_elementwise_fma(av, splat(0.3275911f * 0.70710678118654752440f), splat(1.0f));
+  f32x4 t, e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_rcpf(d[i]);
+  f32x4 q = __builtin_elementwise_fma(splat(1.061405429f), t, splat(-1.453152027f));
+  q = __builtin_elementwise_fma(q, t, splat(1.421413741f));
+  q = __builtin_elementwise_fma(q, t, splat(-0.284496736f));
+  q = __builtin_elementwise_fma(q, t, splat(0.254829592f));
+  const f32x4 z = av * av * (-0.5f * 1.44269504088896340736f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(z[i]);
+  return __builtin_elementwise_fma(av * -0.5f, q * t * e, pos);
 }
 
 template <int RT>
@@ -315,8 +318,21 @@ template <int RQ, int RK>
 DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, int Lk, bool causal,
                    const Lane ln, f32x4 (&ctx)[2][4], float* amap) {
   constexpr int NP = (RQ * RK == 1) ? 4 : (RQ * RK == 2 ? 2 : 1);  // head pairs per group
-  const float scale = 0.35355339059327373f;  // 1/sqrt(8), as float(1./sqrt(E))
-  const bool upper = (ln.c & 8) != 0;        // lane feeds the second head of a pair
+  // softmax(scale * s) is evaluated as 2^(c s + bias - max) / sum with c = scale * log2(e);
+  // bias is 0 for admitted keys and -inf for padded or (causal) future ones.
+  const float c = 0.35355339059327373f * 1.44269504088896340736f;  // float(1/sqrt(8)) * log2 e
+  const bool upper = (ln.c & 8) != 0;  // lane feeds the second head of a pair
+  f32x4 bias[RK][RQ];
+#pragma unroll
+  for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < RQ; ++qt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = 16 * kt + 4 * ln.g + i;
+        const bool ok = key < Lk && (!causal || key <= 16 * qt + ln.c);
+        bias[kt][qt][i] = ok ? 0.f : -INFINITY;
+      }
 #pragma unroll
   for (int hp0 = 0; hp0 < 4; hp0 += NP) {
     f32x4 p[NP][2][RK][RQ];  // [pair][head of the pair][key tile][query tile]
@@ -355,18 +371,13 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
-          const int query = 16 * qt + ln.c;
           float m = -INFINITY;
 #pragma unroll
-          for (int kt = 0; kt < RK; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int key = 16 * kt + 4 * ln.g + i;
-              const bool ok = key < Lk && (!causal || key <= query);
-              const float t = ok ? scale * p[pi][hh][kt][qt][i] : -INFINITY;
-              p[pi][hh][kt][qt][i] = t;
-              m = fmaxf(m, t);
-            }
+          for (int kt = 0; kt < RK; ++kt) {
+            const f32x4 t = __builtin_elementwise_fma(p[pi][hh][kt][qt], splat(c), bias[kt][qt]);
+            p[pi][hh][kt][qt] = t;
+            m = fmaxf(fmaxf(m, fmaxf(t[0], t[1])), fmaxf(t[2], t[3]));
+          }
           mx[pi][hh][qt] = m;
         }
 #pragma unroll
@@ -381,17 +392,17 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
-          float sm = 0.f;
+          f32x4 sm = zero4();
 #pragma unroll
-          for (int kt = 0; kt < RK; ++kt)
+          for (int kt = 0; kt < RK; ++kt) {
+            const f32x4 d = p[pi][hh][kt][qt] - mx[pi][hh][qt];
+            f32x4 e;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float d = p[pi][hh][kt][qt][i] - mx[pi][hh][qt];
-              const float e = (ln.ablate & 4) ? d : __expf(d);
-              p[pi][hh][kt][qt][i] = e;
-              sm += e;
-            }
-          sum[pi][hh][qt] = sm;
+            for (int i = 0; i < 4; ++i) e[i] = (ln.ablate & 4) ? d[i] : __builtin_amdgcn_exp2f(d[i]);
+            p[pi][hh][kt][qt] = e;
+            sm += e;
+          }
+          sum[pi][hh][qt] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
         }
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi)
@@ -407,9 +418,7 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
 #pragma unroll
-          for (int kt = 0; kt < RK; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) p[pi][hh][kt][qt][i] *= sum[pi][hh][qt];
+          for (int kt = 0; kt < RK; ++kt) p[pi][hh][kt][qt] *= sum[pi][hh][qt];
           const int query = 16 * qt + ln.c;
           if (amap && query < Lq) {
             float* row = amap + ((size_t)(2 * (hp0 + pi) + hh) * Lq + query) * Lk;
@@ -463,6 +472,9 @@ constexpr int SZ_ATTN = 4 * (DM * DM + DM);
 constexpr int SZ_FFN = 2 * (DM * DM + DM);
 
 constexpr int SZ_LIN = DM * DM + DM;  // one Linear(64,64): weight | bias
+#ifndef CET_WPS
+#define CET_WPS 2  // waves per SIMD the register budget is set for
+#endif
 #ifndef CET_PIPE
 #define CET_PIPE 0
 #endif
@@ -472,9 +484,7 @@ DEV void activate(f32x4 (&h)[2][4], int activation) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) h[rt][m][i] = act(h[rt][m][i], activation);
+    for (int m = 0; m < 4; ++m) h[rt][m] = act(h[rt][m], activation);
 }
 
 // The layer functions below are written as explicit schedules over two weight-fragment
@@ -850,7 +860,7 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, float* smem, int R, con
 // lengths only shrink along the stack) and run on two row tiles; everything after them runs
 // on one, so the second tile's registers are free for weight prefetching there.
 template <int RD, int RM>
-__global__ __launch_bounds__(64, 2) void informer_kernel(const KArgs a) {
+__global__ __launch_bounds__(64, CET_WPS) void informer_kernel(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x;
 #ifdef CET_PROF
