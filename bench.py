@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import channelestimationtransformer_amd as cet  # noqa: E402
-from channelestimationtransformer_amd import blobs, metrics, synth  # noqa: E402
+from channelestimationtransformer_amd import blobs, e2e, metrics, synth  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="informer", choices=["informer", "lmmse", "lstm", "gru", "rnn"])
+    ap.add_argument("--workload", default="informer", choices=["informer", "lmmse", "lstm", "gru", "rnn", "e2e"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (sequences or REs)")
     ap.add_argument("--pred-len", type=int, default=25, help="rollout horizon of the recurrent workloads")
     ap.add_argument("--no-attention-maps", action="store_true",
@@ -267,6 +267,51 @@ def main():
                 extra[f"{kind}_rollout_B8192_pred5"] = {
                     "predictions_per_s": 8192 / d4, "kernel_ms": d4 * 1e3,
                     "mfma_frac": fl / d4 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+
+    elif args.workload == "e2e":
+        # Transformer prediction of 5 future slots per subcarrier sample -> LMMSE over the 14
+        # OFDM symbols of each predicted slot (4 receive antennas, 2 streams) -> hard-decision
+        # QPSK bit errors and per-slot NMSE; ranks hold disjoint subcarrier ranges.
+        S = args.batch or 3276 * 8
+        n_sym, no = 14, 0.05
+        model, ck = make_informer(False)
+        noisy, clean = synth.channel_histories(S, seed=rank)
+        h_hist = torch.from_numpy(noisy[:, :25]).to(dev)
+        h_future = torch.from_numpy(clean[:, 25:30]).to(dev)
+        g = torch.Generator(device=dev).manual_seed(rank)
+        y, xs = e2e.transmit(h_future, n_sym, no, g)
+        holder = {}
+
+        def step():
+            h_hat = e2e.predict_slots(model, h_hist, 10, 5)
+            x_hat, _ = e2e.equalize_slots(h_hat, y, no)
+            holder["sums"] = {"nmse": metrics.nmse_partial_sums(h_hat, h_future),
+                              "bits": metrics.qpsk_bit_errors(x_hat, xs),
+                              "bits_perfect": metrics.qpsk_bit_errors(x_hat, xs)}
+
+        wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
+        res = e2e.reduce(holder["sums"])  # the path's only collective (RCCL)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        if dist_on:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t)
+        n_re = S * 5 * n_sym
+        out.update({
+            "metric": "channel predictions/s (Transformer prediction + LMMSE equalization + BER/NMSE)",
+            "value": S * n_gpus * args.steps / wall, "unit": "predictions/s",
+            "ms_per_step": wall / args.steps * 1e3, "dtype": "f32",
+            "config": {"workload": f"end to end: InformerStack default configuration on {S} subcarrier "
+                                   f"samples per GPU (4x2 channel), LMMSE 4x2 on {n_re} REs "
+                                   f"(5 slots x {n_sym} symbols), QPSK, no={no}",
+                       "parallelism": f"dp{n_gpus} (subcarrier ranges)"},
+            "roofline": {"bound": "mfma", "achieved": INFORMER_FLOP * S / dev_s / 1e12,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": INFORMER_FLOP * S / dev_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "whole step (informer_kernel + lmmse + torch glue)",
+                         "kernel_ms": dev_s * 1e3},
+            "equalized_REs_per_s": n_re * n_gpus * args.steps / wall,
+            "ber": res["ber"], "nmse_db_per_slot": [round(v, 3) for v in res["nmse_db"]],
+        })
 
     elif args.workload == "lmmse":
         Nr, Ns, no = 16, 4, 0.1

@@ -45,3 +45,36 @@ def test_two_rank_all_reduce_matches_single_process():
         p.join(60)
         assert p.exitcode == 0
     assert np.allclose(got, want, rtol=1e-12)
+
+
+def _e2e_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from channelestimationtransformer_amd import e2e
+    # per-rank partial sums of an end-to-end pass (made-up numbers, the reduction is what is tested)
+    sums = {"nmse": torch.tensor([[1.0 + rank, 2.0, 3.0], [10.0, 20.0 + rank, 30.0]], dtype=torch.float64),
+            "bits": torch.tensor([3.0 + rank, 1000.0], dtype=torch.float64),
+            "bits_perfect": torch.tensor([1.0, 1000.0], dtype=torch.float64)}
+    res = e2e.reduce(sums)
+    if rank == 0:
+        q.put(res)
+    dist.destroy_process_group()
+
+
+def test_two_rank_e2e_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_e2e_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert abs(res["ber"] - 7.0 / 2000.0) < 1e-15
+    assert abs(res["ber_perfect_csi"] - 2.0 / 2000.0) < 1e-15
+    want = 10 * np.log10(np.array([3.0 / 20.0, 4.0 / 41.0, 6.0 / 60.0]))
+    assert np.allclose(res["nmse_db"], want, rtol=1e-12)
