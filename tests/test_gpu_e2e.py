@@ -27,12 +27,21 @@ def _channels(S, seed):
     return (torch.from_numpy(noisy[:, :25]).to(dev), torch.from_numpy(clean[:, 25:]).to(dev), noisy)
 
 
+def _cdl_b_channels():
+    """The reference's stored CDL-B sequences (CR_data_{30,36,60}: 192 x 30 slots of a 4x2
+    channel), the data the shipped checkpoint was trained for."""
+    d = load_npz("cr_pairs.npz")
+    H = np.concatenate([d["data_30"], d["data_36"], d["data_60"]])
+    dev = torch.device("cuda:0")
+    return torch.from_numpy(H[:, :25]).to(dev), torch.from_numpy(H[:, 25:]).to(dev)
+
+
 def test_prediction_step_matches_checker(model, oracle):
     h_hist, _, noisy = _channels(96, 3)
     h_hat = e2e.predict_slots(model, h_hist, 10, 5)
     x_enc = load_batch_np(noisy[:, :25])
     cfg = cfg_from_args(DEFAULT_ARGS, 1)
-    blob = blobs.pack_informer(cfg, dict(load_npz("informer_ckpt.npz")))
+    blob = blobs.pack_informer(dict(load_npz("informer_ckpt.npz")), cfg)
     want, _, _ = oracle.informer_forward(cfg, blob, x_enc, dec_input_np(x_enc, 10, 5))
     want = cet.real2complex(want).reshape(96, 5, 4, 2)
     assert np.abs(h_hat.cpu().numpy() - want).max() < TOL_H
@@ -58,19 +67,21 @@ def test_equalization_step_matches_checker(oracle):
 
 
 def test_end_to_end_properties(model):
-    S = 512
-    h_hist, h_future, _ = _channels(S, 6)
+    h_hist, h_future = _cdl_b_channels()
+    S = h_hist.shape[0]
     sums = e2e.run(model, h_hist, h_future, 10, 5, n_sym=14, no=0.05, seed=1)
     res = e2e.reduce(sums)
     assert sums["bits"][1] == 2 * S * 5 * 14 * 2
     # a noiseless link equalized with the true channel makes no errors
     clean = e2e.run(model, h_hist, h_future, 10, 5, n_sym=14, no=1e-6, seed=1)
     assert clean["bits_perfect"][0] == 0
-    # the predicted channel cannot beat the true one by more than noise, and is far from random
-    assert res["ber_perfect_csi"] <= res["ber"] + 5e-3
-    assert res["ber"] < 0.25
-    assert all(np.isfinite(res["nmse_db"])) and max(res["nmse_db"]) < 0.0
-    # sharding the subcarriers and summing the partial sums gives the same NMSE sums
-    a = e2e.run(model, h_hist[:200], h_future[:200], 10, 5, no=0.05, seed=1)
-    b = e2e.run(model, h_hist[200:], h_future[200:], 10, 5, no=0.05, seed=1)
+    # the reference's own outputs for these sequences reach about -14 dB per slot
+    assert max(res["nmse_db"]) < -12.0
+    # the predicted channel cannot beat the true one by more than noise, and is close to it
+    assert res["ber_perfect_csi"] <= res["ber"] + 2e-3
+    assert res["ber"] < 0.1
+    # sharding the subcarriers and summing the partial sums gives the same sums
+    a = e2e.run(model, h_hist[:100], h_future[:100], 10, 5, no=0.05, seed=1)
+    b = e2e.run(model, h_hist[100:], h_future[100:], 10, 5, no=0.05, seed=1)
     assert torch.allclose(a["nmse"] + b["nmse"], sums["nmse"], rtol=1e-9)
+    assert (a["bits"] + b["bits"])[1] == sums["bits"][1]
