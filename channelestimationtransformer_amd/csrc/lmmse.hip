@@ -6,9 +6,11 @@
 //
 // The job is HBM-bound (688 B and ~2.9 kFLOP per RE at 16x4), so the kernel is built around
 // the memory stream, not around the arithmetic:
-//   * each wave owns a tile of T consecutive REs; H and y of the NEXT tile are pulled
-//     global->LDS by LDS-DMA (global_load_lds, 16 B/lane, 1 KiB per wave instruction, fully
-//     coalesced) while the wave does the arithmetic of the current tile from LDS;
+//   * each wave owns a tile of T consecutive REs; H and y of a tile are pulled global->LDS by
+//     LDS-DMA (global_load_lds, 16 B/lane, 1 KiB per wave instruction, fully coalesced); the
+//     wave copies its operands from LDS to registers, hands the buffer back to the DMA engine
+//     for the next tile at once and does the arithmetic from registers meanwhile (LDS is a
+//     transposing staging area: one 20 KiB buffer per wave, 8 waves per CU);
 //   * the only synchronisation is the wave's own counted s_waitcnt vmcnt(N): tiles are
 //     wave-private, there is no workgroup barrier;
 //   * in LDS the 16-byte chunks of each RE are XOR-permuted (done on the DMA *source*
@@ -19,6 +21,8 @@
 //     Hermitian solve (Cholesky, triangular inverse) in registers.
 // With S = no*I the kernel uses A' = H^H H + no*I, for which d = 1 - no*(A'^-1)_ss and
 // no_eff = t/(1-t), t = no*(A'^-1)_ss: no cancellation in no_eff at high SNR.
+#include <cstdlib>
+
 #include "cet_internal.h"
 
 namespace cet {
@@ -79,9 +83,8 @@ __device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS]
     float d = g.diag[j] + lam;
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= Lr[j][k] * Lr[j][k] + Li[j][k] * Li[j][k];
-    const float ljj = sqrtf(d);
-    inv[j] = 1.0f / ljj;
-    Lr[j][j] = ljj;
+    inv[j] = __builtin_amdgcn_rsqf(d);  // 1 ulp
+    Lr[j][j] = d * inv[j];
     Li[j][j] = 0.f;
 #pragma unroll
     for (int i = j + 1; i < NS; ++i) {
@@ -138,7 +141,7 @@ __device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS]
       a += Wr[k][s] * Wr[k][s] + Wi[k][s] * Wi[k][s];
     }
     const float t = lam * a;
-    const float rd = 1.0f / (1.0f - t);
+    const float rd = __builtin_amdgcn_rcpf(1.0f - t);  // 1 ulp
     xr[s] = zr * rd;
     xi[s] = zi * rd;
     ne[s] = t * rd;
@@ -245,7 +248,6 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
   constexpr int CH = HB / 16, CY = YB / 16;
   constexpr int H_TILE = T * HB, Y_TILE = T * YB;
   constexpr int H_INSTR = H_TILE / 1024, Y_INSTR = Y_TILE / 1024;
-  constexpr int NO_INSTR = PER_RE_NOISE ? 1 : 0;
   constexpr int NO_TILE = PER_RE_NOISE ? 256 : 0;  // T floats, padded to one DMA instruction
   constexpr int BUF = H_TILE + Y_TILE + NO_TILE;
   constexpr int RPP = NR / LPR;           // receive antennas per lane
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
   static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
   static_assert((CH & (CH - 1)) == 0 && (CY & (CY - 1)) == 0, "power-of-two chunk counts");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ __attribute__((aligned(16))) char smem[BUF];
 
   const int lane = threadIdx.x;
   const int t = lane & (T - 1);  // RE within the tile
@@ -274,31 +276,34 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
     yoff[i] = tt * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4);
   }
 
-  auto fill = [&](int buf, long tile) {
+  auto fill = [&](long tile) {
     const long re0 = tile * T;
-    const unsigned hdst = lds_address(smem) + buf * BUF;
+    const unsigned hdst = lds_address(smem);
     const unsigned ydst = hdst + H_TILE;
     const char* hb = reinterpret_cast<const char*>(H) + re0 * HB;
     const char* yb = reinterpret_cast<const char*>(y) + re0 * YB;
-    // A tail tile re-reads the last RE for the missing ones (results are discarded).
     const long last = N - 1 - re0;  // >= T-1 for a full tile
+    if (last >= T - 1) {
 #pragma unroll
-    for (int i = 0; i < H_INSTR; ++i) {
-      unsigned off = hoff[i];
-      if (last < T - 1) {
+      for (int i = 0; i < H_INSTR; ++i) dma16(hb + hoff[i], hdst + i * 1024);
+#pragma unroll
+      for (int i = 0; i < Y_INSTR; ++i) dma16(yb + yoff[i], ydst + i * 1024);
+    } else {
+      // A tail tile re-reads the last RE for the missing ones (results are discarded).
+#pragma unroll
+      for (int i = 0; i < H_INSTR; ++i) {
+        unsigned off = hoff[i];
         const long tt = (i * 64 + lane) / CH;
         if (tt > last) off -= (unsigned)(tt - last) * HB;
+        dma16(hb + off, hdst + i * 1024);
       }
-      dma16(hb + off, hdst + i * 1024);
-    }
 #pragma unroll
-    for (int i = 0; i < Y_INSTR; ++i) {
-      unsigned off = yoff[i];
-      if (last < T - 1) {
+      for (int i = 0; i < Y_INSTR; ++i) {
+        unsigned off = yoff[i];
         const long tt = (i * 64 + lane) / CY;
         if (tt > last) off -= (unsigned)(tt - last) * YB;
+        dma16(yb + off, ydst + i * 1024);
       }
-      dma16(yb + off, ydst + i * 1024);
     }
     if (PER_RE_NOISE) {
       long re = re0 + (lane & (T - 1));
@@ -307,28 +312,53 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
     }
   };
 
-  auto compute = [&](int buf, long tile) {
-    const char* hsrc = smem + buf * BUF + t * HB;
-    const char* ysrc = smem + buf * BUF + H_TILE + t * YB;
+  // This lane's operands of one tile: y of its RPP antennas (two per 16-byte chunk) and the
+  // matching rows of H. Reading them all into registers first frees the LDS buffer for the
+  // next DMA before the arithmetic starts, so two tiles per wave are in flight all the time.
+  constexpr int HV = NS == 1 ? RPP / 2 : RPP * (NS / 2);
+  float4 yreg[RPP / 2], hreg[HV];
+  auto load_regs = [&]() {
+    const char* hsrc = smem + t * HB;
+    const char* ysrc = smem + H_TILE + t * YB;
     const int swh = chunk_swizzle<CH>(t), swy = chunk_swizzle<CY>(t);
-    Gram<NS> g;
-    g.clear();
 #pragma unroll
     for (int rr = 0; rr < RPP; rr += 2) {
-      // y of antennas r, r+1 (one 16-byte chunk)
       const int r = p * RPP + rr;
-      const float4 yv = *reinterpret_cast<const float4*>(ysrc + (((r >> 1) ^ swy) << 4));
-      float hr[2][NS], hi[2][NS];
+      yreg[rr / 2] = *reinterpret_cast<const float4*>(ysrc + (((r >> 1) ^ swy) << 4));
       if (NS == 1) {
-        const float4 hv = *reinterpret_cast<const float4*>(hsrc + (((r >> 1) ^ swh) << 4));
-        hr[0][0] = hv.x; hi[0][0] = hv.y; hr[1][0] = hv.z; hi[1][0] = hv.w;
+        hreg[rr / 2] = *reinterpret_cast<const float4*>(hsrc + (((r >> 1) ^ swh) << 4));
       } else {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int j = 0; j < NS / 2; ++j) {
             const int c = (r + a) * (NS / 2) + j;
-            const float4 hv = *reinterpret_cast<const float4*>(hsrc + ((c ^ swh) << 4));
+            hreg[(rr + a) * (NS / 2) + j] = *reinterpret_cast<const float4*>(hsrc + ((c ^ swh) << 4));
+          }
+      }
+    }
+  };
+  float lam_reg = no_scalar;
+  auto load_noise = [&]() {
+    if (PER_RE_NOISE) lam_reg = *reinterpret_cast<const float*>(smem + H_TILE + Y_TILE + 4 * t);
+  };
+
+  auto compute = [&](long tile) {
+    Gram<NS> g;
+    g.clear();
+#pragma unroll
+    for (int rr = 0; rr < RPP; rr += 2) {
+      const float4 yv = yreg[rr / 2];
+      float hr[2][NS], hi[2][NS];
+      if (NS == 1) {
+        const float4 hv = hreg[rr / 2];
+        hr[0][0] = hv.x; hi[0][0] = hv.y; hr[1][0] = hv.z; hi[1][0] = hv.w;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int j = 0; j < NS / 2; ++j) {
+            const float4 hv = hreg[(rr + a) * (NS / 2) + j];
             hr[a][2 * j] = hv.x; hi[a][2 * j] = hv.y;
             hr[a][2 * j + 1] = hv.z; hi[a][2 * j + 1] = hv.w;
           }
@@ -351,49 +381,66 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
         g.offi[i] += __shfl_xor(g.offi[i], off);
       }
     }
-    float lam = no_scalar;
-    if (PER_RE_NOISE)
-      lam = *reinterpret_cast<const float*>(smem + buf * BUF + H_TILE + Y_TILE + 4 * t);
+    const float lam = lam_reg;
     float xr[NS], xi[NS], ne[NS];
     lmmse_solve<NS>(g, lam, xr, xi, ne);
     const long re = tile * T + t;
     if (re < N) {
-      if (p == 0) {
-        float2* dst = reinterpret_cast<float2*>(x_hat) + re * NS;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      if (LPR == 2 && NS == 4) {
+        // both lanes of an RE hold the full result: lane p writes streams 2p, 2p+1, so every
+        // lane stores 16 B of x_hat and 8 B of no_eff and a wave instruction covers one
+        // contiguous 1 KiB / 512 B block
+        constexpr int S2 = NS >= 4 ? 2 : 0, S3 = NS >= 4 ? 3 : 0;  // (in range for any NS)
+        const v4f xv = p ? v4f{xr[S2], xi[S2], xr[S3], xi[S3]} : v4f{xr[0], xi[0], xr[NS > 1 ? 1 : 0], xi[NS > 1 ? 1 : 0]};
+        const v2f nv = p ? v2f{ne[S2], ne[S3]} : v2f{ne[0], ne[NS > 1 ? 1 : 0]};
+        __builtin_nontemporal_store(xv, reinterpret_cast<v4f*>(x_hat + (re * NS + 2 * p) * 2));
+        __builtin_nontemporal_store(nv, reinterpret_cast<v2f*>(no_eff + re * NS + 2 * p));
+      } else if (p == 0) {
+        float* xd = x_hat + re * NS * 2;
+        float* nd = no_eff + re * NS;
         if (NS % 2 == 0) {
 #pragma unroll
           for (int s = 0; s < NS; s += 2)
-            *reinterpret_cast<float4*>(dst + s) = make_float4(xr[s], xi[s], xr[s + 1], xi[s + 1]);
+            __builtin_nontemporal_store(v4f{xr[s], xi[s], xr[s + 1], xi[s + 1]},
+                                        reinterpret_cast<v4f*>(xd + 2 * s));
         } else {
 #pragma unroll
-          for (int s = 0; s < NS; ++s) dst[s] = make_float2(xr[s], xi[s]);
+          for (int s = 0; s < NS; ++s)
+            __builtin_nontemporal_store(v2f{xr[s], xi[s]}, reinterpret_cast<v2f*>(xd + 2 * s));
         }
-      }
-      if (p == (LPR > 1 ? 1 : 0)) {
-        float* dst = no_eff + re * NS;
         if (NS == 4) {
-          *reinterpret_cast<float4*>(dst) = make_float4(ne[0], ne[1], ne[2], ne[3]);
+          __builtin_nontemporal_store(v4f{ne[0], ne[1], ne[2], ne[3]}, reinterpret_cast<v4f*>(nd));
+        } else if (NS == 2) {
+          __builtin_nontemporal_store(v2f{ne[0], ne[NS > 1 ? 1 : 0]}, reinterpret_cast<v2f*>(nd));
         } else {
-#pragma unroll
-          for (int s = 0; s < NS; ++s) dst[s] = ne[s];
+          __builtin_nontemporal_store(ne[0], nd);
         }
       }
     }
   };
 
+  // One LDS buffer per wave, used as a staging area only. Iteration j: wait for tile j, copy
+  // this lane's operands to registers, hand the buffer straight back to the DMA engine for
+  // tile j + 1, then do the arithmetic of tile j from registers while that DMA is in flight.
+  // vmcnt retires vector-memory instructions (loads, LDS-DMA and stores alike) in issue order;
+  // the only instructions younger than the DMA of tile j are the N_ST output stores of tile
+  // j - 1, which the wait leaves outstanding.
+  constexpr int N_ST = 2;  // at least two store instructions per tile (x_hat, no_eff)
+  const long stride = gridDim.x;
   long tile = blockIdx.x;
-  int buf = 0;
-  if (tile < n_tiles) fill(0, tile);
-  for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
-    const long next = tile + gridDim.x;
-    if (next < n_tiles) {
-      fill(buf ^ 1, next);
-      // everything older than the DMA just issued (this tile's data, earlier stores) is done
-      wait_vmcnt<H_INSTR + Y_INSTR + NO_INSTR>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    compute(buf, tile);
+  if (tile < n_tiles) fill(tile);
+  bool first = true;
+  for (; tile < n_tiles; tile += stride) {
+    if (first) wait_vmcnt<0>();
+    else wait_vmcnt<N_ST>();
+    first = false;
+    load_regs();
+    load_noise();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tile + stride < n_tiles) fill(tile + stride);
+    compute(tile);
   }
 }
 
@@ -405,7 +452,11 @@ int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, c
   int dev = 0, cus = 256;
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  long grid = (long)cus * 8;
+  // resident waves per CU: as many as the LDS staging buffers allow, at most 2 per SIMD
+  constexpr int BUF_BYTES = T * (NR * NS * 8 + NR * 8) + 256;
+  int per_cu = (160 * 1024) / BUF_BYTES;
+  if (per_cu > 8) per_cu = 8;
+  long grid = (long)cus * per_cu;
   if (grid > n_tiles) grid = n_tiles;
   if (no_mode == CET_NO_SCALAR) {
     hipLaunchKernelGGL((lmmse_tiled<NR, NS, LPR, false>), dim3((unsigned)grid), dim3(64), 0, stream,
@@ -450,8 +501,14 @@ int dispatch(const float* y, const float* H, int no_mode, float no_scalar, const
              float* x_hat, float* no_eff, long N, int variant, hipStream_t stream) {
   if (variant == 1 || no_mode == CET_NO_PER_RE_RX)
     return launch_direct<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, stream);
-  return launch_tiled<NR, NS, lanes_per_re<NR, NS>()>(y, H, no_mode, no_scalar, no_dev, x_hat,
-                                                       no_eff, N, stream);
+  constexpr int LPR = lanes_per_re<NR, NS>();
+  static const int lpr_override = [] {
+    const char* e = getenv("CET_LMMSE_LPR");  // timing experiments only
+    return e ? atoi(e) : 0;
+  }();
+  if (LPR == 2 && lpr_override == 1)
+    return launch_tiled<NR, NS, 1>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, stream);
+  return launch_tiled<NR, NS, LPR>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, stream);
 }
 
 }  // namespace

@@ -1,0 +1,115 @@
+// Read-bandwidth ceilings for the access patterns of the LMMSE kernel: plain 16 B/lane loads,
+// LDS-DMA (linear and chunk-swizzled source), different numbers of resident waves.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// grid-stride plain loads, UNROLL independent 1 KiB wave loads in flight per wave
+template <int UNROLL>
+__global__ __launch_bounds__(256) void plain(const f32x4* __restrict__ src, float* out, long n16) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  f32x4 acc{0, 0, 0, 0};
+  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+    f32x4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc += v[u];
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.f) out[0] = 1;
+}
+
+__device__ inline void dma16(const void* src, unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+}
+// one wave per block, tiles of TILE_KB, two buffers; SWZ: XOR the 16-byte chunk index inside
+// each 512-byte record with the record number (the LMMSE kernel's source permutation)
+template <int TILE_KB, bool SWZ, bool CONTIG, int WR = 0>
+__global__ __launch_bounds__(64) void dma(const char* __restrict__ src, float* out, long n_tiles, f32x4* wdst = nullptr) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_KB * 1024];
+  const int lane = threadIdx.x;
+  const unsigned base = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)smem;
+  unsigned off[TILE_KB];
+#pragma unroll
+  for (int i = 0; i < TILE_KB; ++i) {
+    const int P = i * 64 + lane, rec = P / 32, q = P % 32;
+    off[i] = rec * 512 + (((SWZ ? (q ^ (rec & 15)) : q)) << 4);
+  }
+  const long per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  long tile = CONTIG ? blockIdx.x * per : blockIdx.x;
+  const long end = CONTIG ? (tile + per < n_tiles ? tile + per : n_tiles) : n_tiles;
+  const long step = CONTIG ? 1 : gridDim.x;
+  auto fill = [&](int buf, long t) {
+#pragma unroll
+    for (int i = 0; i < TILE_KB; ++i) dma16(src + t * (TILE_KB * 1024L) + off[i], base + buf * TILE_KB * 1024 + i * 1024);
+  };
+  float acc = 0;
+  int buf = 0;
+  if (tile < end) fill(0, tile);
+  for (; tile < end; tile += step, buf ^= 1) {
+    if (tile + step < end) {
+      fill(buf ^ 1, tile + step);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TILE_KB) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    acc += *reinterpret_cast<volatile float*>(smem + buf * TILE_KB * 1024 + lane * 16);
+    // WR: 16-byte stores per lane and tile (1 KiB per wave each), to a separate array
+    if (WR) {
+      f32x4 v{acc, acc, acc, acc};
+#pragma unroll
+      for (int w = 0; w < WR; ++w) {
+        if (WR >= 10) __builtin_nontemporal_store(v, wdst + (tile * (WR - 10 + 1) + w) * 64 + lane);
+        else wdst[(tile * WR + w) * 64 + lane] = v;
+        if (WR >= 10) break;
+      }
+    }
+  }
+  if (acc == 12345.f) out[0] = 1;
+}
+
+template <typename F> void timeit(const char* name, F launch, double bytes) {
+  launch();
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) launch();
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("%-64s %7.1f GB/s\n", name, bytes * 5 / (ms * 1e-3) / 1e9);
+}
+int main() {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  const long bytes = 8L << 30;
+  char* src;
+  float* out;
+  if (hipMalloc(&src, bytes) != hipSuccess) return 1;
+  hipMalloc(&out, 64);
+  hipMemset(src, 1, bytes);
+  const long n16 = bytes / 16;
+  timeit("plain loads, 2048 blocks x 256, unroll 4", [&] { plain<4><<<2048, 256>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("plain loads, 2048 blocks x 256, unroll 8", [&] { plain<8><<<2048, 256>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("plain loads, 4096 blocks x 256, unroll 8", [&] { plain<8><<<4096, 256>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("plain loads, 1024 blocks x 256, unroll 16", [&] { plain<16><<<1024, 256>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("plain loads, 1024 blocks x 64 (1 wave/SIMD), unroll 16", [&] { plain<16><<<1024, 64>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, strided tiles", [&] { dma<16, false, false><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
+  timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, strided, swizzled src", [&] { dma<16, true, false><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
+  timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, contiguous per wave", [&] { dma<16, false, true><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
+  f32x4* wd;
+  hipMalloc(&wd, bytes / 8);
+  timeit("LDS-DMA 16 KiB x2, 1024 waves + 1 KiB store per tile (6%)", [&] { dma<16, false, false, 1><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
+  timeit("LDS-DMA 16 KiB x2, 1024 waves + 1 KiB nt store per tile", [&] { dma<16, false, false, 10><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
+  timeit("LDS-DMA 16 KiB x2, 1024 waves + 2 KiB store per tile (12%)", [&] { dma<16, false, false, 2><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (18.0 / 16));
+  timeit("LDS-DMA 16 KiB tiles x2, 2048 waves (grid), strided", [&] { dma<16, false, false><<<2048, 64>>>(src, out, bytes / 16384); }, bytes);
+  timeit("LDS-DMA 8 KiB tiles x2, 2048 waves resident, strided", [&] { dma<8, false, false><<<2048, 64>>>(src, out, bytes / 8192); }, bytes);
+  timeit("LDS-DMA 8 KiB tiles x2, 2048 waves resident, swizzled", [&] { dma<8, true, false><<<2048, 64>>>(src, out, bytes / 8192); }, bytes);
+  timeit("LDS-DMA 4 KiB tiles x2, 4096 waves resident, strided", [&] { dma<4, false, false><<<4096, 64>>>(src, out, bytes / 4096); }, bytes);
+  return 0;
+}
