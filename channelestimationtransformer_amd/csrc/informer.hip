@@ -32,6 +32,7 @@ namespace cet {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // for 4-byte aligned vector stores
 
 constexpr int DM = 64;    // d_model
 constexpr int NHEAD = 8;  // heads (head dim 8)
@@ -421,14 +422,21 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
           for (int kt = 0; kt < RK; ++kt) p[pi][hh][kt][qt] *= sum[pi][hh][qt];
           const int query = 16 * qt + ln.c;
           if (amap && query < Lq) {
+            // a lane's four consecutive keys go out as one 16-byte store (rows of the map are
+            // only 4-byte aligned; global memory takes unaligned vector stores), the ragged
+            // end of a row as single floats
             float* row = amap + ((size_t)(2 * (hp0 + pi) + hh) * Lq + query) * Lk;
 #pragma unroll
-            for (int kt = 0; kt < RK; ++kt)
+            for (int kt = 0; kt < RK; ++kt) {
+              const int key0 = 16 * kt + 4 * ln.g;
+              if (key0 + 3 < Lk) {
+                *reinterpret_cast<f32x4_u*>(row + key0) = p[pi][hh][kt][qt];
+              } else {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int key = 16 * kt + 4 * ln.g + i;
-                if (key < Lk) row[key] = p[pi][hh][kt][qt][i];
+                for (int i = 0; i < 3; ++i)
+                  if (key0 + i < Lk) row[key0 + i] = p[pi][hh][kt][qt][i];
               }
+            }
           }
         }
     // ---- context^T tile (features 16*hp .. 16*hp+15): A = V^T with the other head's rows
