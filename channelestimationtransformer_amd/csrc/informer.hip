@@ -74,6 +74,9 @@ struct KArgs {
   int mem_rows;
   Op ops[MAX_OPS];
   int ablate;       // timing experiments only (CET_INFORMER_ABLATE): skips parts, wrong results
+  const float* wblk;    // workgroup kernel: staged Linear blocks in consumption order
+  int n_blk;
+  int wave_lds_floats;  // LDS floats private to a wave
   unsigned long long* prof;  // profiling build only
 };
 
@@ -162,6 +165,61 @@ constexpr int PROF_SAMPLES = 16, PROF_MAXM = 1024;
 #endif
 enum { P_EMBED = 0, P_QKV, P_ATTN, P_OPROJ, P_ADDLN, P_FFN, P_DISTIL, P_MOVE, P_PROJ, P_OTHER, P_N };
 
+// Orders this wave's LDS writes before its later LDS reads for the compiler. The hardware
+// executes one wave's LDS instructions in order, and every LDS region below is private to a
+// wave, so no barrier is needed.
+DEV void wave_sync() { asm volatile("" ::: "memory"); }
+
+// ---- weight staging of the workgroup kernel ------------------------------------------------
+// The 8 waves of a workgroup (8 sequences) walk the network in lockstep. The weights of each
+// Linear(64,64) are brought into LDS once per workgroup by LDS-DMA, one product ahead of their
+// use, and every wave reads its MFMA A fragments from there: 1/8 of the vector-memory
+// instructions of the one-wave kernel, whose address path is the shared resource of a CU.
+// Staged block (floats): W[64][LDW] | bias[64] | gamma[64] | beta[64] | pad = 18 KiB.
+constexpr int WBLK = 4608;
+constexpr int WBLK_BIAS = DM * LDW;
+constexpr int WBLK_NORM = WBLK_BIAS + DM;
+constexpr int WG_WAVES = 8;
+struct Stage {
+  const float* blocks;  // global memory: the blocks in consumption order
+  float* buf;           // LDS: two buffers of WBLK floats
+  unsigned lds;         // LDS byte address of buf
+  int next, total;      // next block to request; number of blocks
+  int wave, lane;
+};
+DEV unsigned lds_address(const void* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+// LDS-DMA of 16 B per lane to lds + 16 * lane. Issued through inline asm so that the compiler
+// does not order later LDS reads behind it with vmcnt(0); ordered by stage_acquire's wait.
+DEV void dma16(const void* src, unsigned lds_addr_wave_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_addr_wave_uniform)
+      : "memory");
+}
+// Requests the next block into the buffer (next & 1): 18 wave instructions of 1 KiB, spread
+// over the 8 waves.
+DEV void stage_request(Stage& st) {
+  if (st.next >= st.total) return;
+  const char* src = reinterpret_cast<const char*>(st.blocks + (size_t)st.next * WBLK) + 16 * st.lane;
+  const unsigned dst = st.lds + (st.next & 1) * (WBLK * 4);
+  for (int i = st.wave; i < WBLK * 4 / 1024; i += WG_WAVES) dma16(src + i * 1024, dst + i * 1024);
+  ++st.next;
+}
+// Returns block `next - 1` once it is complete in LDS for the whole workgroup, and requests its
+// successor. The barrier also tells that every wave is done with the block before, whose
+// buffer the new request overwrites.
+DEV const float* stage_acquire(Stage& st) {
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  const float* cur = st.buf + ((st.next - 1) & 1) * WBLK;
+  stage_request(st);
+  return cur;
+}
+
 // out^T[rt][mo] = W[64 x 64] * in^T  (+ bias). W row-major [out][in], bias[out].
 // All 16 weight fragments (and the bias) of the product are requested before the first MFMA:
 // the wave then pays one load latency per product, and the remaining fragments land while the
@@ -199,6 +257,31 @@ DEV void wload(WFrag& f, const float* __restrict__ W, const Lane ln, NormParams*
   }
   if (norm) load_norm(*norm, norm_w, ln);
   __builtin_amdgcn_sched_barrier(0);
+}
+// The same from a staged block in LDS (row stride LDW: conflict-free fragment reads).
+DEV void wload_lds(WFrag& f, const float* blk, const Lane ln, NormParams* norm = nullptr) {
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) f.a[mo][mi] = ld4(blk + (16 * mo + ln.c) * LDW + 16 * mi + 4 * ln.g);
+    f.bv[mo] = ld4(blk + WBLK_BIAS + 16 * mo + 4 * ln.g);
+  }
+  if (norm) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      norm->gm[m] = ld4(blk + WBLK_NORM + 16 * m + 4 * ln.g);
+      norm->bt[m] = ld4(blk + WBLK_NORM + DM + 16 * m + 4 * ln.g);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+// Fragments of the next Linear of the layer: from global memory (one-wave kernel) or from the
+// next staged block (workgroup kernel; the global pointers are then unused).
+template <bool WG>
+DEV void next_weights(WFrag& f, Stage& st, const float* __restrict__ W, const Lane ln,
+                      NormParams* norm = nullptr, const float* __restrict__ norm_w = nullptr) {
+  if (WG) wload_lds(f, stage_acquire(st), ln, norm);
+  else wload(f, W, ln, norm, norm_w);
 }
 // out^T[rt][mo] = W * in^T + bias
 template <int RT>
@@ -315,9 +398,13 @@ DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const f32x4 (&
 // Heads are processed NP pairs at a time, each step for all of them before the next step:
 // scores (MFMA), softmax (VALU, cross-lane), P*V (MFMA). The steps of different heads are
 // independent, so their latencies overlap instead of forming one long dependent chain.
-template <int RQ, int RK>
-DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, int Lk, bool causal,
-                   const Lane ln, f32x4 (&ctx)[2][4], float* amap) {
+// QREG: the queries are not in LDS but in registers (q, T layout). A lane's four features of
+// tile mt then serve directly as B operands, the keys are read as the matching 16-byte groups,
+// and the sum over a tile's 16 features is split into its two heads by zeroing the K operand
+// of the lane groups that hold the other head's features (4 MFMAs of k = 4 per head).
+template <int RQ, int RK, bool QREG>
+DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, const float* Vb, int Lq,
+                   int Lk, bool causal, const Lane ln, f32x4 (&ctx)[2][4], float* amap) {
   constexpr int NP = (RQ * RK == 1) ? 4 : (RQ * RK == 2 ? 2 : 1);  // head pairs per group
   // softmax(scale * s) is evaluated as 2^(c s + bias - max) / sum with c = scale * log2(e);
   // bias is 0 for admitted keys and -inf for padded or (causal) future ones.
@@ -338,32 +425,59 @@ DEV void attention(const float* Qb, const float* Kb, const float* Vb, int Lq, in
   for (int hp0 = 0; hp0 < 4; hp0 += NP) {
     f32x4 p[NP][2][RK][RQ];  // [pair][head of the pair][key tile][query tile]
     // ---- scores^T = K Q^T: lane (query 16*qt + c) holds keys 16*kt + 4*g + i ----
-    float2 kf[NP][2][RK], qf[NP][2][RQ];
+    if (QREG) {
+      f32x4 kf[NP][RK];
 #pragma unroll
-    for (int pi = 0; pi < NP; ++pi)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int col = 8 * (2 * (hp0 + pi) + hh) + 2 * ln.g;  // this lane's two head features
+      for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
         for (int kt = 0; kt < RK; ++kt)
-          kf[pi][hh][kt] = *reinterpret_cast<const float2*>(Kb + (16 * kt + ln.c) * LDW + col);
+          kf[pi][kt] = ld4(Kb + (16 * kt + ln.c) * LDW + 16 * (hp0 + pi) + 4 * ln.g);
+      const bool low = ln.g < 2;  // this lane's features belong to the first head of a pair
 #pragma unroll
-        for (int qt = 0; qt < RQ; ++qt)
-          qf[pi][hh][qt] = *reinterpret_cast<const float2*>(Qb + (16 * qt + ln.c) * LDW + col);
-      }
+      for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-    for (int pi = 0; pi < NP; ++pi)
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+          for (int kt = 0; kt < RK; ++kt) {
+            f32x4 km;
 #pragma unroll
-        for (int kt = 0; kt < RK; ++kt)
+            for (int i = 0; i < 4; ++i) km[i] = ((hh == 0) == low) ? kf[pi][kt][i] : 0.f;
 #pragma unroll
-          for (int qt = 0; qt < RQ; ++qt) {
-            f32x4 sc = zero4();
-            sc = mfma(kf[pi][hh][kt].x, qf[pi][hh][qt].x, sc);
-            sc = mfma(kf[pi][hh][kt].y, qf[pi][hh][qt].y, sc);
-            p[pi][hh][kt][qt] = sc;
+            for (int qt = 0; qt < RQ; ++qt) {
+              f32x4 sc = zero4();
+#pragma unroll
+              for (int i = 0; i < 4; ++i) sc = mfma(km[i], q[qt][hp0 + pi][i], sc);
+              p[pi][hh][kt][qt] = sc;
+            }
           }
+    } else {
+      float2 kf[NP][2][RK], qf[NP][2][RQ];
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int col = 8 * (2 * (hp0 + pi) + hh) + 2 * ln.g;  // this lane's two head features
+#pragma unroll
+          for (int kt = 0; kt < RK; ++kt)
+            kf[pi][hh][kt] = *reinterpret_cast<const float2*>(Kb + (16 * kt + ln.c) * LDW + col);
+#pragma unroll
+          for (int qt = 0; qt < RQ; ++qt)
+            qf[pi][hh][qt] = *reinterpret_cast<const float2*>(Qb + (16 * qt + ln.c) * LDW + col);
+        }
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int kt = 0; kt < RK; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < RQ; ++qt) {
+              f32x4 sc = zero4();
+              sc = mfma(kf[pi][hh][kt].x, qf[pi][hh][qt].x, sc);
+              sc = mfma(kf[pi][hh][kt].y, qf[pi][hh][qt].y, sc);
+              p[pi][hh][kt][qt] = sc;
+            }
+    }
     // ---- masked, scaled softmax over the keys of each query ----
     float mx[NP][2][RQ], sum[NP][2][RQ];
 #pragma unroll
@@ -483,9 +597,6 @@ constexpr int SZ_LIN = DM * DM + DM;  // one Linear(64,64): weight | bias
 #ifndef CET_WPS
 #define CET_WPS 2  // waves per SIMD the register budget is set for
 #endif
-#ifndef CET_PIPE
-#define CET_PIPE 0
-#endif
 
 template <int RT>
 DEV void activate(f32x4 (&h)[2][4], int activation) {
@@ -495,90 +606,62 @@ DEV void activate(f32x4 (&h)[2][4], int activation) {
     for (int m = 0; m < 4; ++m) h[rt][m] = act(h[rt][m], activation);
 }
 
-// The layer functions below are written as explicit schedules over two weight-fragment
-// buffers A and B: while the MFMAs of one product run from one buffer, the fragments of the
-// next product are already on their way into the other. A layer pays the load latency once,
-// at its first two products.
+// LDS regions of a wave: one-wave kernel Q | K | V (R rows each), workgroup kernel K | V (the
+// queries stay in registers). A padded tile read may run into the next region (finite data).
+template <bool WG>
+DEV float* region_q(float* smem, int R) { return smem; }
+template <bool WG>
+DEV float* region_k(float* smem, int R) { return WG ? smem : smem + R * LDW; }
+template <bool WG>
+DEV float* region_v(float* smem, int R) { return WG ? smem + R * LDW : smem + 2 * R * LDW; }
 
-// Stores the three projections of an attention layer into the Q | K | V regions.
-// PIPE: the fragments of product n+1 are requested before the MFMAs of product n (two
-// buffers); otherwise one buffer is loaded and used in turn (half the registers).
-// On return with PIPE, B holds the fragments of the output projection.
-template <int RQ, int RK, bool PIPE>
-DEV void project_qkv(const float* __restrict__ w, float* smem, int R, const Lane ln,
-                     const f32x4 (&xq)[2][4], const f32x4 (&xkv)[2][4], int Lq, int Lk, WFrag& A,
-                     WFrag& B, bool a_loaded) {
-  float* Qb = smem;  // R rows each; a padded tile read may run into the next region (finite data)
-  float* Kb = smem + R * LDW;
-  float* Vb = smem + 2 * R * LDW;
+// The three projections of an attention layer: K and V go to LDS, Q to LDS (one-wave kernel)
+// or stays in registers (workgroup kernel).
+template <int RQ, int RK, bool WG>
+DEV void project_qkv(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
+                     const f32x4 (&xq)[2][4], const f32x4 (&xkv)[2][4], int Lq, int Lk,
+                     f32x4 (&q)[2][4]) {
+  WFrag A;
   f32x4 t[2][4];
-  __syncthreads();  // earlier readers of the Q/K/V regions are done
-  if (PIPE) {
-    if (!a_loaded) wload(A, w, ln);
-    wload(B, w + SZ_LIN, ln);
-    wmul<RQ>(A, xq, t);
-    store_rows<RQ>(Qb, ln, t, Lq);
-    wload(A, w + 2 * SZ_LIN, ln);
-    wmul<RK>(B, xkv, t);
-    store_rows<RK>(Kb, ln, t, Lk);
-    wload(B, w + 3 * SZ_LIN, ln);
-    wmul<RK>(A, xkv, t);
-    store_rows<RK>(Vb, ln, t, Lk);
-  } else {
-    wload(A, w, ln);
-    wmul<RQ>(A, xq, t);
-    store_rows<RQ>(Qb, ln, t, Lq);
-    wload(A, w + SZ_LIN, ln);
-    wmul<RK>(A, xkv, t);
-    store_rows<RK>(Kb, ln, t, Lk);
-    wload(A, w + 2 * SZ_LIN, ln);
-    wmul<RK>(A, xkv, t);
-    store_rows<RK>(Vb, ln, t, Lk);
-  }
-  __syncthreads();
+  wave_sync();  // earlier reads of the regions are issued
+  next_weights<WG>(A, st, w, ln);
+  wmul<RQ>(A, xq, q);
+  if (!WG) store_rows<RQ>(region_q<WG>(smem, R), ln, q, Lq);
+  next_weights<WG>(A, st, w + SZ_LIN, ln);
+  wmul<RK>(A, xkv, t);
+  store_rows<RK>(region_k<WG>(smem, R), ln, t, Lk);
+  next_weights<WG>(A, st, w + 2 * SZ_LIN, ln);
+  wmul<RK>(A, xkv, t);
+  store_rows<RK>(region_v<WG>(smem, R), ln, t, Lk);
+  wave_sync();
   PROF_MARK(ln, P_QKV);
 }
 
 // EncoderLayer.forward (encoder.py:37-53) with AttentionLayer / FullAttention (attn.py).
 // Block: q,k,v,o Linear | conv1 | conv2 | norm1 g,b | norm2 g,b.
 constexpr int SZ_ENC_LAYER = SZ_ATTN + SZ_FFN + 4 * DM;
-template <int RT>
-DEV void encoder_layer(const float* __restrict__ w, float* smem, int R, const Lane ln, int L,
-                       int activation, float* amap, f32x4 (&x)[2][4]) {
-  constexpr bool PIPE = CET_PIPE && RT == 1;
+template <int RT, bool WG>
+DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
+                       int L, int activation, float* amap, f32x4 (&x)[2][4]) {
   const float* nw = w + SZ_ATTN + SZ_FFN;
-  WFrag A, B;
+  WFrag A;
   NormParams n;
   f32x4 t[2][4], y[2][4];
-  project_qkv<RT, RT, PIPE>(w, smem, R, ln, x, x, L, L, A, B, false);
-  attention<RT, RT>(smem, smem + R * LDW, smem + 2 * R * LDW, L, L, false, ln, y, amap);
+  project_qkv<RT, RT, WG>(w, st, smem, R, ln, x, x, L, L, t);
+  attention<RT, RT, WG>(t, region_q<WG>(smem, R), region_k<WG>(smem, R), region_v<WG>(smem, R), L, L,
+                        false, ln, y, amap);
   PROF_MARK(ln, P_ATTN);
-  if (PIPE) {
-    wload(A, w + SZ_ATTN, ln, &n, nw);  // conv1, norm1
-    wmul<RT>(B, y, t);                  // output projection
-    PROF_MARK(ln, P_OPROJ);
-    wload(B, w + SZ_ATTN + SZ_LIN, ln);  // conv2
-    add_into<RT>(x, t);
-    layer_norm<RT>(x, n, ln);
-    load_norm(n, nw + 2 * DM, ln);  // norm2
-    __builtin_amdgcn_sched_barrier(0);
-    PROF_MARK(ln, P_ADDLN);
-    wmul<RT>(A, x, t);
-    activate<RT>(t, activation);
-    wmul<RT>(B, t, y);
-  } else {
-    wload(A, w + 3 * SZ_LIN, ln, &n, nw);
-    wmul<RT>(A, y, t);
-    PROF_MARK(ln, P_OPROJ);
-    add_into<RT>(x, t);
-    layer_norm<RT>(x, n, ln);
-    PROF_MARK(ln, P_ADDLN);
-    wload(A, w + SZ_ATTN, ln);
-    wmul<RT>(A, x, t);
-    activate<RT>(t, activation);
-    wload(A, w + SZ_ATTN + SZ_LIN, ln, &n, nw + 2 * DM);
-    wmul<RT>(A, t, y);
-  }
+  next_weights<WG>(A, st, w + 3 * SZ_LIN, ln, &n, nw);  // output projection, norm1
+  wmul<RT>(A, y, t);
+  PROF_MARK(ln, P_OPROJ);
+  add_into<RT>(x, t);
+  layer_norm<RT>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+  next_weights<WG>(A, st, w + SZ_ATTN, ln);  // conv1
+  wmul<RT>(A, x, t);
+  activate<RT>(t, activation);
+  next_weights<WG>(A, st, w + SZ_ATTN + SZ_LIN, ln, &n, nw + 2 * DM);  // conv2, norm2
+  wmul<RT>(A, t, y);
   PROF_MARK(ln, P_FFN);
   add_into<RT>(x, y);
   layer_norm<RT>(x, n, ln);
@@ -588,64 +671,43 @@ DEV void encoder_layer(const float* __restrict__ w, float* smem, int R, const La
 // DecoderLayer.forward (decoder.py:20-36).
 // Block: self q,k,v,o | cross q,k,v,o | conv1 | conv2 | norm1 | norm2 | norm3.
 constexpr int SZ_DEC_LAYER = 2 * SZ_ATTN + SZ_FFN + 6 * DM;
-template <int RD, int RM>
-DEV void decoder_layer(const float* __restrict__ w, float* smem, int R, const Lane ln, int Ld,
-                       int Lm, int activation, const f32x4 (&mem)[2][4], f32x4 (&x)[2][4]) {
-  constexpr bool PIPE = CET_PIPE && RD == 1 && RM == 1;
-  float* Qb = smem;
-  float* Kb = smem + R * LDW;
-  float* Vb = smem + 2 * R * LDW;
+template <int RD, int RM, bool WG>
+DEV void decoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
+                       int Ld, int Lm, int activation, const f32x4 (&mem)[2][4], f32x4 (&x)[2][4]) {
+  float* Qb = region_q<WG>(smem, R);
+  float* Kb = region_k<WG>(smem, R);
+  float* Vb = region_v<WG>(smem, R);
   const float* wc = w + SZ_ATTN;       // cross attention
   const float* wf = w + 2 * SZ_ATTN;   // conv1 | conv2
   const float* nw = wf + SZ_FFN;
-  WFrag A, B;
+  WFrag A;
   NormParams n;
   f32x4 t[2][4], y[2][4];
   // causal self attention
-  project_qkv<RD, RD, PIPE>(w, smem, R, ln, x, x, Ld, Ld, A, B, false);
-  attention<RD, RD>(Qb, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
+  project_qkv<RD, RD, WG>(w, st, smem, R, ln, x, x, Ld, Ld, t);
+  attention<RD, RD, WG>(t, Qb, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
-  if (PIPE) {
-    wload(A, wc, ln, &n, nw);  // cross q, norm1
-    wmul<RD>(B, y, t);
-  } else {
-    wload(A, w + 3 * SZ_LIN, ln, &n, nw);
-    wmul<RD>(A, y, t);
-  }
+  next_weights<WG>(A, st, w + 3 * SZ_LIN, ln, &n, nw);  // output projection, norm1
+  wmul<RD>(A, y, t);
   PROF_MARK(ln, P_OPROJ);
   add_into<RD>(x, t);
   layer_norm<RD>(x, n, ln);
   PROF_MARK(ln, P_ADDLN);
   // cross attention: queries from x, keys / values from the encoder memory
-  project_qkv<RD, RM, PIPE>(wc, smem, R, ln, x, mem, Ld, Lm, A, B, PIPE);
-  attention<RD, RM>(Qb, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
+  project_qkv<RD, RM, WG>(wc, st, smem, R, ln, x, mem, Ld, Lm, t);
+  attention<RD, RM, WG>(t, Qb, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
-  if (PIPE) {
-    wload(A, wf, ln, &n, nw + 2 * DM);  // conv1, norm2
-    wmul<RD>(B, y, t);
-    PROF_MARK(ln, P_OPROJ);
-    wload(B, wf + SZ_LIN, ln);  // conv2
-    add_into<RD>(x, t);
-    layer_norm<RD>(x, n, ln);
-    load_norm(n, nw + 4 * DM, ln);  // norm3
-    __builtin_amdgcn_sched_barrier(0);
-    PROF_MARK(ln, P_ADDLN);
-    wmul<RD>(A, x, t);
-    activate<RD>(t, activation);
-    wmul<RD>(B, t, y);
-  } else {
-    wload(A, wc + 3 * SZ_LIN, ln, &n, nw + 2 * DM);
-    wmul<RD>(A, y, t);
-    PROF_MARK(ln, P_OPROJ);
-    add_into<RD>(x, t);
-    layer_norm<RD>(x, n, ln);
-    PROF_MARK(ln, P_ADDLN);
-    wload(A, wf, ln);
-    wmul<RD>(A, x, t);
-    activate<RD>(t, activation);
-    wload(A, wf + SZ_LIN, ln, &n, nw + 4 * DM);
-    wmul<RD>(A, t, y);
-  }
+  next_weights<WG>(A, st, wc + 3 * SZ_LIN, ln, &n, nw + 2 * DM);  // output projection, norm2
+  wmul<RD>(A, y, t);
+  PROF_MARK(ln, P_OPROJ);
+  add_into<RD>(x, t);
+  layer_norm<RD>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+  next_weights<WG>(A, st, wf, ln);  // conv1
+  wmul<RD>(A, x, t);
+  activate<RD>(t, activation);
+  next_weights<WG>(A, st, wf + SZ_LIN, ln, &n, nw + 4 * DM);  // conv2, norm3
+  wmul<RD>(A, t, y);
   PROF_MARK(ln, P_FFN);
   add_into<RD>(x, y);
   layer_norm<RD>(x, n, ln);
@@ -656,16 +718,56 @@ DEV void decoder_layer(const float* __restrict__ w, float* smem, int R, const La
 // (eval; folded to alpha/beta) -> ELU -> MaxPool1d(3, 2, 1). L rows in, returns rows out.
 // Block: w[3][64][64] (tap-major) | bias | alpha | beta.
 constexpr int SZ_DISTIL = 3 * DM * DM + 3 * DM;
-template <int RT>  // tiles covering L + 2 conv outputs
-DEV int distil(const float* __restrict__ w, float* smem, int R, const Lane ln, int L,
+// Workgroup kernel: the three taps are three staged blocks (tap 0 carries the conv bias and,
+// in its gamma | beta slots, alpha | beta); each is one accumulating product over the rows
+// shifted by that tap.
+template <int RT, bool WG>  // tiles covering L + 2 conv outputs
+DEV int distil(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln, int L,
                f32x4 (&x)[2][4]) {
   float* Xb = smem;            // L input rows
-  float* Yb = smem + R * LDW;  // L + 2 activated conv outputs (R + L + 2 <= 3 R)
-  __syncthreads();
+  float* Yb = smem + R * LDW;  // L + 2 activated conv outputs (R + L + 2 rows in all)
+  wave_sync();
   store_rows<RT>(Xb, ln, x, L);
-  __syncthreads();
+  wave_sync();
   const int Lc = L + 2;
   f32x4 y[2][4];
+  if (WG) {
+    NormParams ab;  // gm = alpha, bt = beta
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      WFrag A;
+      wload_lds(A, stage_acquire(st), ln, j == 0 ? &ab : nullptr);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        int t = 16 * rt + ln.c;
+        t = t < Lc ? t : Lc - 1;
+        int src = t + j - 2;  // circular padding of 2 on both sides
+        src = src < 0 ? src + L : src;
+        src = src >= L ? src - L : src;
+        f32x4 bf[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) bf[mi] = ld4(Xb + src * LDW + 16 * mi + 4 * ln.g);
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) {
+          f32x4 acc = j == 0 ? A.bv[mo] : y[rt][mo];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = mfma(A.a[mo][mi][i], bf[mi][i], acc);
+          y[rt][mo] = acc;
+        }
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = y[rt][mo][i] * ab.gm[mo][i] + ab.bt[mo][i];
+          y[rt][mo][i] = v > 0.f ? v : (__expf(v) - 1.0f);
+        }
+  } else {
   // Weight fragments of one 16-feature output block (3 taps x 4 k-blocks) plus its bias and
   // folded BatchNorm vectors; requested one block ahead of the MFMAs that use them.
   struct Block {
@@ -722,8 +824,9 @@ DEV int distil(const float* __restrict__ w, float* smem, int R, const Lane ln, i
     compute(b0, 2);
     compute(b1, 3);
   }
+  }
   store_rows<RT>(Yb, ln, y, Lc);
-  __syncthreads();
+  wave_sync();
   const int Lo = (Lc - 1) / 2 + 1;
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
@@ -752,12 +855,12 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
                const Lane ln, int lane, int L, f32x4 (&x)[2][4]) {
   constexpr int CIN = 16 * NKB;
   constexpr int XW = CIN + 4;  // staging row stride
-  __syncthreads();
+  wave_sync();
   for (int i = lane; i < L * (CIN / 4); i += 64) {
     const int r = i / (CIN / 4), c4 = i % (CIN / 4);
     st4(smem + r * XW + 4 * c4, ld4(xg + (size_t)r * CIN + 4 * c4));
   }
-  __syncthreads();
+  wave_sync();
   const float* bias = w + 3 * DM * CIN;
   const float* pe = bias + DM;
   // all weight fragments (3 taps x NKB k-blocks x 4 output blocks) are requested up front
@@ -810,9 +913,9 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
 template <int RS, int RD>
 DEV void move_rows(float* smem, const Lane ln, const f32x4 (&x)[2][4], int first, int n, int dst,
                    f32x4 (&into)[2][4]) {
-  __syncthreads();
+  wave_sync();
   store_rows<RS>(smem, ln, x, first + n);
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int rt = 0; rt < RD; ++rt) {
     const int r = 16 * rt + ln.c;
@@ -832,9 +935,9 @@ struct Cursor {
 };
 
 // One encoder step on RT row tiles (RM: tiles of the memory).
-template <int RT, int RM>
-DEV void run_op(const Op op, const KArgs& a, Cursor& cu, float* smem, int R, const Lane ln, int b,
-                f32x4 (&x)[2][4], f32x4 (&mem)[2][4]) {
+template <int RT, int RM, bool WG>
+DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem, int R, const Lane ln,
+                int b, f32x4 (&x)[2][4], f32x4 (&mem)[2][4]) {
   const int L = op.L;
   if (op.type == OP_LAYER) {
     float* amap = nullptr;
@@ -842,11 +945,11 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, float* smem, int R, con
       amap = cu.attn + (size_t)b * NHEAD * L * L;
       cu.attn += (size_t)a.B * NHEAD * L * L;
     }
-    encoder_layer<RT>(cu.w, smem, R, ln, L, a.activation, amap, x);
+    encoder_layer<RT, WG>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
     if (!(a.ablate & 8)) cu.w += SZ_ENC_LAYER;
     tap<RT>(cu.taps, a.B, b, L, ln, x);
   } else if (op.type == OP_DISTIL) {
-    const int Lo = distil<RT>(cu.w, smem, R, ln, L, x);
+    const int Lo = distil<RT, WG>(cu.w, st, smem, R, ln, L, x);
     cu.w += SZ_DISTIL;
     tap<RT>(cu.taps, a.B, b, Lo, ln, x);
     PROF_MARK(ln, P_DISTIL);
@@ -866,29 +969,38 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, float* smem, int R, con
 // One wave = one sequence. RD / RM: row tiles of the decoder sequence / of the encoder memory
 // (known on the host). The encoder steps that touch more than 16 rows come first (sequence
 // lengths only shrink along the stack) and run on two row tiles; everything after them runs
-// on one, so the second tile's registers are free for weight prefetching there.
-template <int RD, int RM>
-__global__ __launch_bounds__(64, CET_WPS) void informer_kernel(const KArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x;
+// on one.
+// WG = false: a workgroup is one wave; every wave loads its weights from global memory.
+// WG = true: a workgroup is 8 waves that keep in step through the weight staging (Stage);
+// waves beyond the batch compute a copy of the last sequence and store nothing.
+template <int RD, int RM, bool WG>
+__global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void informer_kernel(const KArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = WG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  const int R = a.region_rows;
+  const int seq = WG ? (int)blockIdx.x * WG_WAVES + wave : (int)blockIdx.x;
+  const bool valid = seq < a.B;
+  const int b = valid ? seq : a.B - 1;
+  float* smem = WG ? smem_all + 2 * WBLK + wave * a.wave_lds_floats : smem_all;
 #ifdef CET_PROF
   int prof_idx = 0;
   const int prof_stride = a.B >= PROF_SAMPLES ? a.B / PROF_SAMPLES : 1;
-  const int prof_slot = (int)blockIdx.x / prof_stride;
-  const bool prof_on = (int)blockIdx.x % prof_stride == 0 && prof_slot < PROF_SAMPLES;
+  const int prof_slot = seq / prof_stride;
+  const bool prof_on = valid && seq % prof_stride == 0 && prof_slot < PROF_SAMPLES;
   const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)),
                 prof_on ? a.prof + (size_t)prof_slot * PROF_MAXM : nullptr, &prof_idx};
   PROF_MARK(ln, P_OTHER);
 #else
   const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4))};
 #endif
-  const int R = a.region_rows;
-  const int b = blockIdx.x;
+  Stage st{a.wblk, smem_all, WG ? lds_address(smem_all) : 0u, 0, WG ? a.n_blk : 0, wave, lane};
+  if (WG) stage_request(st);  // block 0 travels while the embedding is computed
 
   // Rows the padded 16-row tiles may touch must hold finite numbers from the start.
-  for (int i = lane; i < 3 * R * LDW / 4; i += 64) st4(smem + 4 * i, zero4());
+  for (int i = lane; i < a.wave_lds_floats / 4; i += 64) st4(smem + 4 * i, zero4());
 
-  Cursor cu{a.w, a.attn, a.taps};
+  Cursor cu{a.w, valid ? a.attn : nullptr, valid ? a.taps : nullptr};
   f32x4 x[2][4], mem[2][4];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -917,8 +1029,8 @@ __global__ __launch_bounds__(64, CET_WPS) void informer_kernel(const KArgs a) {
 
   // ---- encoder stack (encoder.py:87-101) ---------------------------------------------
   int i = 0;
-  for (; i < a.n_ops2; ++i) run_op<2, RM>(a.ops[i], a, cu, smem, R, ln, b, x, mem);
-  for (; i < a.n_ops; ++i) run_op<1, RM>(a.ops[i], a, cu, smem, R, ln, b, x, mem);
+  for (; i < a.n_ops2; ++i) run_op<2, RM, WG>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  for (; i < a.n_ops; ++i) run_op<1, RM, WG>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
   tap<RM>(cu.taps, a.B, b, a.mem_rows, ln, mem);
 
   // ---- decoder ---------------------------------------------------------------------
@@ -930,7 +1042,7 @@ __global__ __launch_bounds__(64, CET_WPS) void informer_kernel(const KArgs a) {
     PROF_MARK(ln, P_EMBED);
   }
   for (int l = 0; l < a.d_layers; ++l) {
-    decoder_layer<RD, RM>(cu.w, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
+    decoder_layer<RD, RM, WG>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
     if (!(a.ablate & 8)) cu.w += SZ_DEC_LAYER;
     tap<RD>(cu.taps, a.B, b, Ld, ln, x);
   }
@@ -958,7 +1070,7 @@ __global__ __launch_bounds__(64, CET_WPS) void informer_kernel(const KArgs a) {
         for (int i2 = 0; i2 < 4; ++i2) acc = mfma(wa[mi][i2], x[rt][mi][i2], acc);
       const int r = 16 * rt + ln.c;
       const int f0 = 16 * mo + 4 * ln.g;
-      if (r >= Ld - a.pred_len && r < Ld && f0 < a.c_out)
+      if (valid && r >= Ld - a.pred_len && r < Ld && f0 < a.c_out)
         st4(a.out + ((size_t)b * a.pred_len + (r - (Ld - a.pred_len))) * a.c_out + f0, acc);
     }
   }
@@ -974,6 +1086,8 @@ struct InformerModel {
   cet_informer_cfg cfg;
   Dims d;
   float* dev_blob = nullptr;
+  float* dev_blocks = nullptr;  // staged Linear blocks of the workgroup kernel
+  int n_blocks = 0;
   size_t attn_per_sample = 0;  // floats
   size_t taps_per_sample = 0;
 };
@@ -1077,6 +1191,17 @@ int informer_create(const cet_informer_cfg* c, const float* wsrc, size_t n, Info
     copy(D);
     copy((size_t)emb_len[s] * D);
   }
+  // Staged blocks of the workgroup kernel, in consumption order: every Linear(64,64) as
+  // W[64][LDW] | bias | gamma | beta (the LayerNorm that follows it, if any) | zero padding.
+  std::vector<float> blk;
+  auto add_block = [&](const float* lin, const float* norm) {
+    const size_t base = blk.size();
+    blk.resize(base + WBLK, 0.f);
+    for (int r = 0; r < DM; ++r) std::copy(lin + (size_t)r * DM, lin + (size_t)(r + 1) * DM, blk.begin() + base + (size_t)r * LDW);
+    std::copy(lin + D * D, lin + D * D + D, blk.begin() + base + WBLK_BIAS);
+    if (norm) std::copy(norm, norm + 2 * D, blk.begin() + base + WBLK_NORM);
+  };
+  const size_t lin_sz = D * D + D;
   const size_t layer_sz = 4 * (D * D + D) + 2 * (D * D + D) + 4 * D;
   for (int e = 0; e < d.n_enc; ++e) {
     const int el = d.enc_layers[e];
@@ -1084,6 +1209,14 @@ int informer_create(const cet_informer_cfg* c, const float* wsrc, size_t n, Info
     const float* convs = p + layer_sz * el;
     for (int l = 0; l < el; ++l) {
       v.insert(v.end(), layers + layer_sz * l, layers + layer_sz * (l + 1));
+      {
+        const float* lw = layers + layer_sz * l;       // q k v o conv1 conv2 norm1 norm2
+        const float* norms = lw + 6 * lin_sz;
+        for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr);
+        add_block(lw + 3 * lin_sz, norms);
+        add_block(lw + 4 * lin_sz, nullptr);
+        add_block(lw + 5 * lin_sz, norms + 2 * D);
+      }
       if (c->distil && l < el - 1) {
         const float* cw = convs + (size_t)l * (3 * D * D + 5 * D);
         conv_taps_major(cw, DM, DM, v);
@@ -1098,12 +1231,34 @@ int informer_create(const cet_informer_cfg* c, const float* wsrc, size_t n, Info
         }
         v.insert(v.end(), alpha.begin(), alpha.end());
         v.insert(v.end(), beta.begin(), beta.end());
+        // staged: one block per tap (the taps-major copy just appended to v is [3][out][in])
+        {
+          const size_t taps_at = v.size() - (3 * D * D + 3 * D);
+          std::vector<float> lin(D * D + D), ab(2 * D);
+          std::copy(alpha.begin(), alpha.end(), ab.begin());
+          std::copy(beta.begin(), beta.end(), ab.begin() + D);
+          for (int j = 0; j < 3; ++j) {
+            std::copy(v.begin() + taps_at + (size_t)j * D * D, v.begin() + taps_at + (size_t)(j + 1) * D * D, lin.begin());
+            for (size_t i = 0; i < D; ++i) lin[D * D + i] = j == 0 ? cb[i] : 0.f;
+            add_block(lin.data(), j == 0 ? ab.data() : nullptr);
+          }
+        }
       }
     }
     p = convs + (c->distil ? (size_t)(el - 1) * (3 * D * D + 5 * D) : 0);
     copy(2 * D);  // encoder norm
   }
-  copy((size_t)c->d_layers * (2 * 4 * (D * D + D) + 2 * (D * D + D) + 6 * D));
+  for (int l = 0; l < c->d_layers; ++l) {
+    const float* lw = p;  // self q k v o | cross q k v o | conv1 conv2 | norm1 norm2 norm3
+    const float* norms = lw + 10 * lin_sz;
+    for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr);
+    add_block(lw + 3 * lin_sz, norms);
+    for (int k = 4; k < 7; ++k) add_block(lw + k * lin_sz, nullptr);
+    add_block(lw + 7 * lin_sz, norms + 2 * D);
+    add_block(lw + 8 * lin_sz, nullptr);
+    add_block(lw + 9 * lin_sz, norms + 4 * D);
+    copy(10 * lin_sz + 6 * D);
+  }
   copy(2 * D);  // decoder norm
   {
     const int rows = (c->c_out + 15) / 16 * 16;
@@ -1123,11 +1278,16 @@ int informer_create(const cet_informer_cfg* c, const float* wsrc, size_t n, Info
   m->d = d;
   for (int i = 0; i < d.n_attn; ++i) m->attn_per_sample += (size_t)NHEAD * d.attn_len[i] * d.attn_len[i];
   for (int i = 0; i < d.n_taps; ++i) m->taps_per_sample += (size_t)d.tap_rows[i] * DM;
+  m->n_blocks = (int)(blk.size() / WBLK);
   hipError_t e = hipMalloc(&m->dev_blob, v.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(m->dev_blob, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&m->dev_blocks, blk.size() * sizeof(float));
+  if (e == hipSuccess)
+    e = hipMemcpy(m->dev_blocks, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (m->dev_blob) (void)hipFree(m->dev_blob);
+    if (m->dev_blocks) (void)hipFree(m->dev_blocks);
     delete m;
     return hip_fail(e);
   }
@@ -1138,6 +1298,7 @@ int informer_create(const cet_informer_cfg* c, const float* wsrc, size_t n, Info
 void informer_destroy(InformerModel* m) {
   if (!m) return;
   if (m->dev_blob) (void)hipFree(m->dev_blob);
+  if (m->dev_blocks) (void)hipFree(m->dev_blocks);
   delete m;
 }
 
@@ -1183,19 +1344,36 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     a.n_ops2 = n2;
     a.mem_rows = mem_rows;
   }
-  // LDS: three regions of R rows (Q | K | V; also the conv / max-pool staging, which needs
-  // L + (L + 2) rows, and the staging of move_rows).
+  // LDS of a wave. One-wave kernel: three regions of R rows (Q | K | V), which also cover the
+  // conv / max-pool staging (L + (L + 2) rows) and the staging of move_rows. Workgroup kernel:
+  // K | V (2 R rows) or the conv staging (R + R + 2 rows), next to the two weight buffers.
   const int Ld = m->d.label_len + m->d.pred_len;
   int R = m->d.seq_len > Ld ? m->d.seq_len : Ld;
   if (R < m->d.mem_rows) R = m->d.mem_rows;
   if (R < 12) R = 12;
   a.region_rows = R;
-  const size_t lds = (size_t)3 * R * LDW * sizeof(float);
+  a.wblk = m->dev_blocks;
+  a.n_blk = m->n_blocks;
   static const int ablate = [] {
     const char* e = getenv("CET_INFORMER_ABLATE");
     return e ? atoi(e) : 0;
   }();
   a.ablate = ablate;
+  // CET_INFORMER_KERNEL=one_wave | workgroup overrides the choice below (tests, timing); read
+  // on every call so that a test can switch between the two.
+  const char* force = getenv("CET_INFORMER_KERNEL");
+  const bool force_one = force && force[0] == 'o', force_wg = force && force[0] == 'w';
+  const size_t wg_wave_bytes = (size_t)(2 * R + 2) * LDW * sizeof(float);
+  const size_t wg_lds = 2 * WBLK * sizeof(float) + WG_WAVES * wg_wave_bytes;
+  // The workgroup kernel fills a CU with 8 sequences; below about 5 sequences per CU the
+  // one-wave kernel, which spreads single waves over all CUs, finishes sooner.
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    CET_HIP(hipGetDevice(&dev));
+    CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const bool wg = wg_lds <= 160 * 1024 && !force_one && (force_wg || B > 5 * cus);
 #ifdef CET_PROF
   static unsigned long long* prof_dev = nullptr;
   const size_t prof_bytes = (size_t)PROF_SAMPLES * PROF_MAXM * sizeof(unsigned long long);
@@ -1204,11 +1382,35 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   a.prof = prof_dev;
 #endif
   const bool d2 = Ld > 16, m2 = a.mem_rows > 16;
-  const dim3 grid((unsigned)B), block(64);
-  if (!d2 && !m2) hipLaunchKernelGGL((informer_kernel<1, 1>), grid, block, lds, stream, a);
-  else if (!d2 && m2) hipLaunchKernelGGL((informer_kernel<1, 2>), grid, block, lds, stream, a);
-  else if (d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 1>), grid, block, lds, stream, a);
-  else hipLaunchKernelGGL((informer_kernel<2, 2>), grid, block, lds, stream, a);
+  if (wg) {
+    a.wave_lds_floats = (int)(wg_wave_bytes / sizeof(float));
+    const dim3 grid((unsigned)((B + WG_WAVES - 1) / WG_WAVES)), block(64 * WG_WAVES);
+#define CET_LAUNCH_WG(RD_, RM_)                                                                  \
+  do {                                                                                           \
+    static bool attr_set[64] = {};                                                               \
+    int dev = 0;                                                                                 \
+    CET_HIP(hipGetDevice(&dev));                                                                 \
+    if (dev < 64 && !attr_set[dev]) {                                                            \
+      CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<RD_, RM_, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+      attr_set[dev] = true;                                                                      \
+    }                                                                                            \
+    hipLaunchKernelGGL((informer_kernel<RD_, RM_, true>), grid, block, wg_lds, stream, a);       \
+  } while (0)
+    if (!d2 && !m2) CET_LAUNCH_WG(1, 1);
+    else if (!d2 && m2) CET_LAUNCH_WG(1, 2);
+    else if (d2 && !m2) CET_LAUNCH_WG(2, 1);
+    else CET_LAUNCH_WG(2, 2);
+#undef CET_LAUNCH_WG
+  } else {
+    a.wave_lds_floats = 3 * R * LDW;
+    const size_t lds = (size_t)a.wave_lds_floats * sizeof(float);
+    const dim3 grid((unsigned)B), block(64);
+    if (!d2 && !m2) hipLaunchKernelGGL((informer_kernel<1, 1, false>), grid, block, lds, stream, a);
+    else if (!d2 && m2) hipLaunchKernelGGL((informer_kernel<1, 2, false>), grid, block, lds, stream, a);
+    else if (d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 1, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((informer_kernel<2, 2, false>), grid, block, lds, stream, a);
+  }
   CET_HIP(hipGetLastError());
 #ifdef CET_PROF
   {
