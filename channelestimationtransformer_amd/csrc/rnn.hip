@@ -41,7 +41,16 @@ DEV f32x16 mfma32(float a, float b, f32x16 c) {
 }
 DEV f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 DEV void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-DEV float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// Gate non-linearities on the hardware exp2 / rcp (1 ulp each): absolute error ~1e-7, the size of
+// the fp32 rounding the recurrence carries anyway. exp2 of a large argument gives inf and
+// rcp(inf) = 0, so both saturate correctly.
+DEV float sigmoidf_(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
+}
+DEV float tanhf_(float v) {
+  const float t = __builtin_amdgcn_exp2f(-2.0f * 1.44269504088896340736f * fabsf(v));  // e^(-2|v|)
+  return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
+}
 
 template <int KIND> struct Cell;
 template <> struct Cell<CET_RNN_TANH> { static constexpr int G = 1, NACC = 1; };
@@ -242,20 +251,20 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
         for (int r = 0; r < 16; ++r) {
           float hv;
           if (KIND == CET_RNN_TANH) {
-            hv = tanhf(acc[0][r]);
+            hv = tanhf_(acc[0][r]);
           } else if (KIND == CET_RNN_GRU) {
             const float rg = sigmoidf_(acc[0][r]);
             const float zg = sigmoidf_(acc[1][r]);
-            const float ng = tanhf(acc[2][r] + rg * acc[3][r]);
+            const float ng = tanhf_(acc[2][r] + rg * acc[3][r]);
             hv = (1.0f - zg) * ng + zg * hprev[r];
           } else {
             const float ig = sigmoidf_(acc[0][r]);
             const float fg = sigmoidf_(acc[1][r]);
-            const float gg = tanhf(acc[2][r]);
+            const float gg = tanhf_(acc[2][r]);
             const float og = sigmoidf_(acc[3][r]);
             const float cv = fg * cst[LSTM ? l : 0][LSTM ? u : 0][r] + ig * gg;
             cst[LSTM ? l : 0][LSTM ? u : 0][r] = cv;
-            hv = og * tanhf(cv);
+            hv = og * tanhf_(cv);
           }
           hnew[u][r] = hv;
         }
