@@ -77,6 +77,7 @@ struct KArgs {
   const float* wblk;    // workgroup kernel: staged Linear blocks in consumption order
   int n_blk;
   int wave_lds_floats;  // LDS floats private to a wave
+  int n_pack0;          // workgroup kernel: first step that runs on packed tiles (n_ops: none)
   unsigned long long* prof;  // profiling build only
 };
 
@@ -402,9 +403,13 @@ DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const f32x4 (&
 // tile mt then serve directly as B operands, the keys are read as the matching 16-byte groups,
 // and the sum over a tile's 16 features is split into its two heads by zeroing the K operand
 // of the lane groups that hold the other head's features (4 MFMAs of k = 4 per head).
+// pack_L > 0 (single tiles only): the tile holds two sequences of pack_L <= 8 rows, at rows
+// 0.. and 8..; a query then only admits the keys of its own sequence, and amap / amap2 are the
+// maps of the first / second sequence (Lq = Lk = 16 for the row bookkeeping).
 template <int RQ, int RK, bool QREG>
 DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, const float* Vb, int Lq,
-                   int Lk, bool causal, const Lane ln, f32x4 (&ctx)[2][4], float* amap) {
+                   int Lk, bool causal, const Lane ln, f32x4 (&ctx)[2][4], float* amap,
+                   int pack_L = 0, float* amap2 = nullptr) {
   constexpr int NP = (RQ * RK == 1) ? 4 : (RQ * RK == 2 ? 2 : 1);  // head pairs per group
   // softmax(scale * s) is evaluated as 2^(c s + bias - max) / sum with c = scale * log2(e);
   // bias is 0 for admitted keys and -inf for padded or (causal) future ones.
@@ -418,7 +423,8 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int key = 16 * kt + 4 * ln.g + i;
-        const bool ok = key < Lk && (!causal || key <= 16 * qt + ln.c);
+        bool ok = key < Lk && (!causal || key <= 16 * qt + ln.c);
+        if (pack_L) ok = (key >> 3) == (ln.c >> 3) && (key & 7) < pack_L;
         bias[kt][qt][i] = ok ? 0.f : -INFINITY;
       }
 #pragma unroll
@@ -535,7 +541,19 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
 #pragma unroll
           for (int kt = 0; kt < RK; ++kt) p[pi][hh][kt][qt] *= sum[pi][hh][qt];
           const int query = 16 * qt + ln.c;
-          if (amap && query < Lq) {
+          if (pack_L) {
+            // rows of a map are at most 8 floats here: single stores
+            float* mp = (ln.c >> 3) ? amap2 : amap;
+            const int ql = ln.c & 7;
+            if (mp && ql < pack_L) {
+              float* row = mp + ((size_t)(2 * (hp0 + pi) + hh) * pack_L + ql) * pack_L;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int kl = 4 * ln.g + i - 8 * (ln.c >> 3);
+                if (kl >= 0 && kl < pack_L) row[kl] = p[pi][hh][0][qt][i];
+              }
+            }
+          } else if (amap && query < Lq) {
             // a lane's four consecutive keys go out as one 16-byte store (rows of the map are
             // only 4-byte aligned; global memory takes unaligned vector stores), the ragged
             // end of a row as single floats
@@ -642,14 +660,15 @@ DEV void project_qkv(const float* __restrict__ w, Stage& st, float* smem, int R,
 constexpr int SZ_ENC_LAYER = SZ_ATTN + SZ_FFN + 4 * DM;
 template <int RT, bool WG>
 DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
-                       int L, int activation, float* amap, f32x4 (&x)[2][4]) {
+                       int L, int activation, float* amap, f32x4 (&x)[2][4], int pack_L = 0,
+                       float* amap2 = nullptr) {
   const float* nw = w + SZ_ATTN + SZ_FFN;
   WFrag A;
   NormParams n;
   f32x4 t[2][4], y[2][4];
   project_qkv<RT, RT, WG>(w, st, smem, R, ln, x, x, L, L, t);
   attention<RT, RT, WG>(t, region_q<WG>(smem, R), region_k<WG>(smem, R), region_v<WG>(smem, R), L, L,
-                        false, ln, y, amap);
+                        false, ln, y, amap, pack_L, amap2);
   PROF_MARK(ln, P_ATTN);
   next_weights<WG>(A, st, w + 3 * SZ_LIN, ln, &n, nw);  // output projection, norm1
   wmul<RT>(A, y, t);
@@ -927,6 +946,87 @@ DEV void move_rows(float* smem, const Lane ln, const f32x4 (&x)[2][4], int first
   }
 }
 
+// ---- two sequences in one tile ------------------------------------------------------------
+// In the workgroup kernel waves w and w + 4 run on the same SIMD, one after the other. Once
+// the rows per sequence are down to 8 or fewer, wave w (the primary) takes the rows of wave
+// w + 4 (the partner) into rows 8.. of its tile and carries both sequences through the rest of
+// the encoder stack with the MFMA work of one; the partner only keeps the weight staging going.
+// The encoder outputs of the second sequence travel back through the partner's LDS region.
+
+DEV void exchange_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// tap() for a packed tile: rows 0.. belong to sequence b, rows 8.. to sequence b2 (-1: none).
+DEV void tap_packed(float*& taps, int B, int b, int b2, int rows, const Lane ln,
+                    const f32x4 (&x)[2][4]) {
+  if (!taps) return;
+  const int bs = (ln.c >> 3) ? b2 : b, rl = ln.c & 7;
+  if (bs >= 0 && rl < rows) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      st4(taps + ((size_t)bs * rows + rl) * DM + 16 * m + 4 * ln.g, x[0][m]);
+  }
+  taps += (size_t)B * rows * DM;
+}
+
+// distil() for a packed tile (L + 2 <= 8 conv outputs per sequence). Returns rows out.
+DEV int distil_packed(Stage& st, float* smem, int R, const Lane ln, int L, f32x4 (&x)[2][4]) {
+  float* Xb = smem;
+  float* Yb = smem + R * LDW;
+  wave_sync();
+  store_rows<1>(Xb, ln, x, 16);
+  wave_sync();
+  const int Lc = L + 2;
+  const int base = ln.c & 8;
+  int t = ln.c & 7;
+  t = t < Lc ? t : Lc - 1;
+  f32x4 y[2][4];
+  NormParams ab;  // gm = alpha, bt = beta
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    WFrag A;
+    wload_lds(A, stage_acquire(st), ln, j == 0 ? &ab : nullptr);
+    int src = t + j - 2;  // circular padding of 2 on both sides, inside the own sequence
+    src = src < 0 ? src + L : src;
+    src = src >= L ? src - L : src;
+    f32x4 bf[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) bf[mi] = ld4(Xb + (base + src) * LDW + 16 * mi + 4 * ln.g);
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) {
+      f32x4 acc = j == 0 ? A.bv[mo] : y[0][mo];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = mfma(A.a[mo][mi][i], bf[mi][i], acc);
+      y[0][mo] = acc;
+    }
+  }
+#pragma unroll
+  for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = y[0][mo][i] * ab.gm[mo][i] + ab.bt[mo][i];
+      y[0][mo][i] = v > 0.f ? v : (__expf(v) - 1.0f);
+    }
+  store_rows<1>(Yb, ln, y, 16);
+  wave_sync();
+  const int Lo = (Lc - 1) / 2 + 1;
+  int u = ln.c & 7;
+  u = u < Lo ? u : Lo - 1;
+  const int r0 = base + (2 * u - 1 < 0 ? 0 : 2 * u - 1);  // window rows clipped to the sequence
+  const int r1 = base + 2 * u;
+  const int r2 = base + (2 * u + 1 > Lc - 1 ? Lc - 1 : 2 * u + 1);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x4 a = ld4(Yb + r0 * LDW + 16 * m + 4 * ln.g);
+    const f32x4 b = ld4(Yb + r1 * LDW + 16 * m + 4 * ln.g);
+    const f32x4 c = ld4(Yb + r2 * LDW + 16 * m + 4 * ln.g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[0][m][i] = fmaxf(fmaxf(a[i], b[i]), c[i]);
+  }
+  return Lo;
+}
+
 // State that the steps of the encoder stack advance.
 struct Cursor {
   const float* w;  // next weight block
@@ -963,6 +1063,68 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
   } else {
     move_rows<RT, RT>(smem, ln, x, op.a, op.b, 0, x);
     PROF_MARK(ln, P_MOVE);
+  }
+}
+
+// One encoder step of the primary wave on a packed tile (sequences b and b2; b2 = -1: none).
+template <int RM>
+DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
+                       float* partner_smem, int R, const Lane ln, int b, int b2, f32x4 (&x)[2][4],
+                       f32x4 (&mem)[2][4]) {
+  const int L = op.L;
+  if (op.type == OP_LAYER) {
+    float *amap = nullptr, *amap2 = nullptr;
+    if (cu.attn) {
+      if (b >= 0) amap = cu.attn + (size_t)b * NHEAD * L * L;
+      if (b2 >= 0) amap2 = cu.attn + (size_t)b2 * NHEAD * L * L;
+      cu.attn += (size_t)a.B * NHEAD * L * L;
+    }
+    encoder_layer<1, true>(cu.w, st, smem, R, ln, 16, a.activation, amap, x, L, amap2);
+    cu.w += SZ_ENC_LAYER;
+    tap_packed(cu.taps, a.B, b, b2, L, ln, x);
+  } else if (op.type == OP_DISTIL) {
+    const int Lo = distil_packed(st, smem, R, ln, L, x);
+    cu.w += SZ_DISTIL;
+    tap_packed(cu.taps, a.B, b, b2, Lo, ln, x);
+  } else {  // OP_NORM_APPEND (the host packs no other step)
+    layer_norm<1>(x, cu.w, cu.w + DM, ln);
+    cu.w += 2 * DM;
+    tap_packed(cu.taps, a.B, b, b2, L, ln, x);
+    move_rows<1, RM>(smem, ln, x, 0, L, op.a, mem);
+    // the second sequence's rows go back through the partner's region
+    store_rows<1>(partner_smem, ln, x, 16);
+    exchange_barrier();
+  }
+}
+// The same step seen from the partner wave: it keeps its share of the weight staging and the
+// barriers, advances the cursors and collects its encoder outputs.
+template <int RM>
+DEV void run_op_partner(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
+                        const Lane ln, f32x4 (&mem)[2][4]) {
+  const int L = op.L;
+  if (op.type == OP_LAYER) {
+    for (int k = 0; k < 6; ++k) stage_acquire(st);
+    if (cu.attn) cu.attn += (size_t)a.B * NHEAD * L * L;
+    cu.w += SZ_ENC_LAYER;
+    if (cu.taps) cu.taps += (size_t)a.B * L * DM;
+  } else if (op.type == OP_DISTIL) {
+    for (int k = 0; k < 3; ++k) stage_acquire(st);
+    cu.w += SZ_DISTIL;
+    const int Lo = (L + 1) / 2 + 1;
+    if (cu.taps) cu.taps += (size_t)a.B * Lo * DM;
+  } else {
+    cu.w += 2 * DM;
+    if (cu.taps) cu.taps += (size_t)a.B * L * DM;
+    exchange_barrier();
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt) {
+      const int r = 16 * rt + ln.c;
+      if (r >= op.a && r < op.a + L) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          mem[rt][m] = ld4(smem + (8 + r - op.a) * LDW + 16 * m + 4 * ln.g);
+      }
+    }
   }
 }
 
@@ -1030,7 +1192,30 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   // ---- encoder stack (encoder.py:87-101) ---------------------------------------------
   int i = 0;
   for (; i < a.n_ops2; ++i) run_op<2, RM, WG>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
-  for (; i < a.n_ops; ++i) run_op<1, RM, WG>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  const int n_plain = WG ? a.n_pack0 : a.n_ops;
+  for (; i < n_plain; ++i) run_op<1, RM, WG>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  if (WG && i < a.n_ops) {
+    // hand the partner's rows to the primary (see "two sequences in one tile")
+    const int L0 = a.ops[i].L;
+    if (wave >= WG_WAVES / 2) {
+      wave_sync();
+      store_rows<1>(smem, ln, x, L0);
+      exchange_barrier();
+      for (; i < a.n_ops; ++i) run_op_partner<RM>(a.ops[i], a, cu, st, smem, ln, mem);
+    } else {
+      float* partner_smem = smem + (WG_WAVES / 2) * a.wave_lds_floats;
+      const int seq2 = seq + WG_WAVES / 2;
+      exchange_barrier();
+      if (ln.c >= 8 && ln.c < 8 + L0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          x[0][m] = ld4(partner_smem + (ln.c - 8) * LDW + 16 * m + 4 * ln.g);
+      }
+      for (; i < a.n_ops; ++i)
+        run_op_packed<RM>(a.ops[i], a, cu, st, smem, partner_smem, R, ln, valid ? b : -1,
+                          seq2 < a.B ? seq2 : -1, x, mem);
+    }
+  }
   tap<RM>(cu.taps, a.B, b, a.mem_rows, ln, mem);
 
   // ---- decoder ---------------------------------------------------------------------
@@ -1343,6 +1528,19 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     a.n_ops = n;
     a.n_ops2 = n2;
     a.mem_rows = mem_rows;
+    // Packed tail of the step list: from the first step on after which every layer has at
+    // most 8 rows, every distil at most 8 conv outputs, and nothing is sliced.
+    int p0 = n;
+    for (int k = n - 1; k >= n2; --k) {
+      const Op& o = a.ops[k];
+      const bool ok = (o.type == OP_LAYER && o.L <= 8) || (o.type == OP_DISTIL && o.L + 2 <= 8) ||
+                      (o.type == OP_NORM_APPEND && o.L <= 8);
+      if (!ok) break;
+      p0 = k;
+    }
+    while (p0 < n && a.ops[p0].type != OP_LAYER) ++p0;  // start at a layer
+    const char* pk = getenv("CET_INFORMER_PACK");       // "0" disables (tests, timing)
+    a.n_pack0 = (pk && pk[0] == '0') ? n : p0;
   }
   // LDS of a wave. One-wave kernel: three regions of R rows (Q | K | V), which also cover the
   // conv / max-pool staging (L + (L + 2) rows) and the staging of move_rows. Workgroup kernel:
