@@ -968,54 +968,63 @@ DEV void tap_packed(float*& taps, int B, int b, int b2, int rows, const Lane ln,
   taps += (size_t)B * rows * DM;
 }
 
-// distil() for a packed tile (L + 2 <= 8 conv outputs per sequence). Returns rows out.
-DEV int distil_packed(Stage& st, float* smem, int R, const Lane ln, int L, f32x4 (&x)[2][4]) {
-  float* Xb = smem;
-  float* Yb = smem + R * LDW;
+// distil() for a packed tile (L <= 8 rows per sequence). NT = 1: the L + 2 <= 8 conv outputs of
+// both sequences fit one tile (rows 0.. and 8..); NT = 2: up to 10 outputs per sequence, tile s
+// holds those of sequence s. The pooled rows are packed again. Returns rows out.
+template <int NT>
+DEV int distil_packed(Stage& st, float* smem, const Lane ln, int L, f32x4 (&x)[2][4]) {
+  float* Xb = smem;             // 16 input rows
+  float* Yb = smem + 16 * LDW;  // NT tiles of activated conv outputs
   wave_sync();
   store_rows<1>(Xb, ln, x, 16);
   wave_sync();
   const int Lc = L + 2;
-  const int base = ln.c & 8;
-  int t = ln.c & 7;
-  t = t < Lc ? t : Lc - 1;
   f32x4 y[2][4];
   NormParams ab;  // gm = alpha, bt = beta
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     WFrag A;
     wload_lds(A, stage_acquire(st), ln, j == 0 ? &ab : nullptr);
-    int src = t + j - 2;  // circular padding of 2 on both sides, inside the own sequence
-    src = src < 0 ? src + L : src;
-    src = src >= L ? src - L : src;
-    f32x4 bf[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) bf[mi] = ld4(Xb + (base + src) * LDW + 16 * mi + 4 * ln.g);
+    for (int rt = 0; rt < NT; ++rt) {
+      const int base = NT == 1 ? (ln.c & 8) : 8 * rt;  // first input row of the lane's sequence
+      int t = NT == 1 ? (ln.c & 7) : ln.c;
+      t = t < Lc ? t : Lc - 1;
+      int src = t + j - 2;  // circular padding of 2 on both sides, inside the own sequence
+      src = src < 0 ? src + L : src;
+      src = src >= L ? src - L : src;
+      f32x4 bf[4];
 #pragma unroll
-    for (int mo = 0; mo < 4; ++mo) {
-      f32x4 acc = j == 0 ? A.bv[mo] : y[0][mo];
+      for (int mi = 0; mi < 4; ++mi) bf[mi] = ld4(Xb + (base + src) * LDW + 16 * mi + 4 * ln.g);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mo = 0; mo < 4; ++mo) {
+        f32x4 acc = j == 0 ? A.bv[mo] : y[rt][mo];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = mfma(A.a[mo][mi][i], bf[mi][i], acc);
-      y[0][mo] = acc;
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = mfma(A.a[mo][mi][i], bf[mi][i], acc);
+        y[rt][mo] = acc;
+      }
     }
   }
 #pragma unroll
-  for (int mo = 0; mo < 4; ++mo)
+  for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float v = y[0][mo][i] * ab.gm[mo][i] + ab.bt[mo][i];
-      y[0][mo][i] = v > 0.f ? v : (__expf(v) - 1.0f);
-    }
-  store_rows<1>(Yb, ln, y, 16);
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = y[rt][mo][i] * ab.gm[mo][i] + ab.bt[mo][i];
+        y[rt][mo][i] = v > 0.f ? v : (__expf(v) - 1.0f);
+      }
+  store_rows<NT>(Yb, ln, y, 16 * NT);
   wave_sync();
   const int Lo = (Lc - 1) / 2 + 1;
+  const int ybase = NT == 1 ? (ln.c & 8) : 2 * (ln.c & 8);  // first output row of the sequence
   int u = ln.c & 7;
   u = u < Lo ? u : Lo - 1;
-  const int r0 = base + (2 * u - 1 < 0 ? 0 : 2 * u - 1);  // window rows clipped to the sequence
-  const int r1 = base + 2 * u;
-  const int r2 = base + (2 * u + 1 > Lc - 1 ? Lc - 1 : 2 * u + 1);
+  const int r0 = ybase + (2 * u - 1 < 0 ? 0 : 2 * u - 1);  // window rows clipped to the sequence
+  const int r1 = ybase + 2 * u;
+  const int r2 = ybase + (2 * u + 1 > Lc - 1 ? Lc - 1 : 2 * u + 1);
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const f32x4 a = ld4(Yb + r0 * LDW + 16 * m + 4 * ln.g);
@@ -1083,7 +1092,7 @@ DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float
     cu.w += SZ_ENC_LAYER;
     tap_packed(cu.taps, a.B, b, b2, L, ln, x);
   } else if (op.type == OP_DISTIL) {
-    const int Lo = distil_packed(st, smem, R, ln, L, x);
+    const int Lo = L + 2 <= 8 ? distil_packed<1>(st, smem, ln, L, x) : distil_packed<2>(st, smem, ln, L, x);
     cu.w += SZ_DISTIL;
     tap_packed(cu.taps, a.B, b, b2, Lo, ln, x);
   } else {  // OP_NORM_APPEND (the host packs no other step)
@@ -1528,12 +1537,12 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     a.n_ops = n;
     a.n_ops2 = n2;
     a.mem_rows = mem_rows;
-    // Packed tail of the step list: from the first step on after which every layer has at
-    // most 8 rows, every distil at most 8 conv outputs, and nothing is sliced.
+    // Packed tail of the step list: from the first step on after which every layer and distil
+    // step has at most 8 rows per sequence and nothing is sliced.
     int p0 = n;
     for (int k = n - 1; k >= n2; --k) {
       const Op& o = a.ops[k];
-      const bool ok = (o.type == OP_LAYER && o.L <= 8) || (o.type == OP_DISTIL && o.L + 2 <= 8) ||
+      const bool ok = (o.type == OP_LAYER && o.L <= 8) || (o.type == OP_DISTIL && o.L <= 8) ||
                       (o.type == OP_NORM_APPEND && o.L <= 8);
       if (!ok) break;
       p0 = k;
