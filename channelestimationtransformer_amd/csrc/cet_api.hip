@@ -170,4 +170,15 @@ int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scala
   return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, 1, stream);
 }
 
+int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, int P, int C,
+                  void* stream) {
+  if (!pred || !truth || !sums || B < 0 || P < 1 || C < 4 || C % 4) return CET_ERR_INVALID_ARG;
+  return nmse_sums_launch(pred, truth, sums, B, P, C, static_cast<hipStream_t>(stream));
+}
+
+int cet_qpsk_bit_errors(const float* x_hat, const float* x_true, double* out, long N, void* stream) {
+  if (!x_hat || !x_true || !out || N < 0) return CET_ERR_INVALID_ARG;
+  return qpsk_errors_launch(x_hat, x_true, out, N, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -28,6 +28,11 @@ int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, c
                  float* x_hat, float* no_eff, long N, int Nr, int Ns, int variant,
                  hipStream_t stream);
 
+int nmse_sums_launch(const float* pred, const float* truth, double* sums, long B, int P, int C,
+                     hipStream_t stream);
+int qpsk_errors_launch(const float* x_hat, const float* x_true, double* out, long N,
+                       hipStream_t stream);
+
 }  // namespace cet
 
 struct cet_handle_s {

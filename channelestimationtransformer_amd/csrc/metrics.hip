@@ -1,0 +1,88 @@
+// Evaluation sums on the GPU: per-slot NMSE partial sums and hard-decision QPSK bit errors.
+// They are what a rank contributes to the one all-reduce of an evaluation
+// (HPC/python/Evaluate.py:172-177 forms NMSE_s = sum_err_s / sum_pow_s over batch and antennas;
+// LocalSimulations/EndtoEndtest.py:196-200 counts bit errors). HBM-bound single pass: every
+// input element is read once, reduced in fp64 inside a wave and added with one atomic per wave.
+#include "cet_internal.h"
+
+namespace cet {
+namespace {
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// pred, truth [B][P][C] fp32 (C % 4 == 0). blockIdx.y = slot p. sums[0][p] += sum (t-p)^2,
+// sums[1][p] += sum t^2.
+__global__ __launch_bounds__(256) void nmse_sums_kernel(const float* __restrict__ pred,
+                                                        const float* __restrict__ truth,
+                                                        double* __restrict__ sums, long B, int P,
+                                                        int C) {
+  const int p = blockIdx.y;
+  const int c4 = C / 4;
+  const long n = B * c4;  // float4 items of this slot
+  double err = 0.0, pow = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / c4;
+    const int q = (int)(i - b * c4);
+    const size_t at = ((size_t)b * P + p) * C + 4 * q;
+    const float4 a = *reinterpret_cast<const float4*>(pred + at);
+    const float4 t = *reinterpret_cast<const float4*>(truth + at);
+    const double d0 = (double)t.x - a.x, d1 = (double)t.y - a.y, d2 = (double)t.z - a.z,
+                 d3 = (double)t.w - a.w;
+    err += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    pow += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
+  }
+  err = wave_sum(err);
+  pow = wave_sum(pow);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(sums + p, err);
+    atomicAdd(sums + P + p, pow);
+  }
+}
+
+// x_hat, x_true [N] complex64 (interleaved). out[0] += bit errors of the hard decisions
+// (real > 0, imag > 0), out[1] += 2 N.
+__global__ __launch_bounds__(256) void qpsk_errors_kernel(const float2* __restrict__ x_hat,
+                                                          const float2* __restrict__ x_true,
+                                                          double* __restrict__ out, long N) {
+  unsigned cnt = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+    const float2 a = x_hat[i], t = x_true[i];
+    cnt += ((a.x > 0.f) != (t.x > 0.f)) + ((a.y > 0.f) != (t.y > 0.f));
+  }
+  const double s = wave_sum((double)cnt);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out + 1, 2.0 * (double)N);
+}
+
+}  // namespace
+
+int nmse_sums_launch(const float* pred, const float* truth, double* sums, long B, int P, int C,
+                     hipStream_t stream) {
+  CET_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)P * sizeof(double), stream));
+  if (B == 0) return CET_OK;
+  long blocks = (B * (C / 4) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(nmse_sums_kernel, dim3((unsigned)blocks, (unsigned)P), dim3(256), 0, stream, pred,
+                     truth, sums, B, P, C);
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+
+int qpsk_errors_launch(const float* x_hat, const float* x_true, double* out, long N,
+                       hipStream_t stream) {
+  CET_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), stream));
+  if (N == 0) return CET_OK;
+  long blocks = (N + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(qpsk_errors_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                     reinterpret_cast<const float2*>(x_hat), reinterpret_cast<const float2*>(x_true),
+                     out, N);
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+
+}  // namespace cet

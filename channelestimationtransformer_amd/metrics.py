@@ -1,4 +1,8 @@
-"""NMSE / BER bookkeeping: per-rank partial sums on the GPU, one all-reduce across ranks."""
+"""NMSE / BER bookkeeping: per-rank partial sums on the GPU, one all-reduce across ranks.
+
+On ROCm tensors the sums come from the HIP reduction kernels (csrc/metrics.hip, fp64
+accumulation); tensors on the CPU (host-side bookkeeping, the gloo tests) take the equivalent
+torch expressions."""
 import torch
 
 
@@ -9,6 +13,10 @@ def nmse_partial_sums(pred, truth):
     if torch.is_complex(pred):
         pred, truth = torch.view_as_real(pred), torch.view_as_real(truth)
     B, P = pred.shape[0], pred.shape[1]
+    if pred.is_cuda and pred.dtype == torch.float32 and truth.dtype == torch.float32 and B > 0 \
+            and (pred[0, 0].numel() % 4 == 0):
+        from . import ops  # noqa: F401
+        return torch.ops.cet.nmse_sums(pred.reshape(B, P, -1), truth.reshape(B, P, -1))
     d = (truth.double() - pred.double()).reshape(B, P, -1)
     t = truth.double().reshape(B, P, -1)
     return torch.stack([(d * d).sum(dim=(0, 2)), (t * t).sum(dim=(0, 2))])
@@ -16,6 +24,10 @@ def nmse_partial_sums(pred, truth):
 
 def qpsk_bit_errors(x_hat, x_true):
     """Hard-decision QPSK: bit errors and bit count, float64 [2]."""
+    if x_hat.is_cuda and x_hat.dtype == torch.complex64 and x_true.dtype == torch.complex64:
+        from . import ops  # noqa: F401
+        return torch.ops.cet.qpsk_bit_errors(torch.view_as_real(x_hat.contiguous()),
+                                             torch.view_as_real(x_true.contiguous()))
     e = ((x_hat.real > 0) != (x_true.real > 0)).sum() + ((x_hat.imag > 0) != (x_true.imag > 0)).sum()
     return torch.stack([e.double(), torch.tensor(2.0 * x_hat.numel(), dtype=torch.float64,
                                                  device=x_hat.device)])

@@ -94,3 +94,43 @@ def lmmse(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: float,
 def _(y, H, no, no_scalar, no_mode, direct):
     N, Ns = H.shape[0], H.shape[2]
     return y.new_empty((N, Ns, 2)), y.new_empty((N, Ns))
+
+
+@torch.library.custom_op("cet::nmse_sums", mutates_args=())
+def nmse_sums(pred: torch.Tensor, truth: torch.Tensor) -> torch.Tensor:
+    """pred, truth [B,P,C] float32 -> float64 [2,P]: (sum (truth-pred)^2, sum truth^2) per slot."""
+    dev = _dev_check(pred, truth)
+    pred = pred.contiguous().float()
+    truth = truth.contiguous().float()
+    B, P, C = pred.shape
+    sums = torch.empty((2, P), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().cet_nmse_sums(_ptr(pred), _ptr(truth), ctypes.c_void_p(sums.data_ptr()),
+                                       ctypes.c_long(B), P, C, _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_nmse_sums")
+    return sums
+
+
+@nmse_sums.register_fake
+def _(pred, truth):
+    return pred.new_empty((2, pred.shape[1]), dtype=torch.float64)
+
+
+@torch.library.custom_op("cet::qpsk_bit_errors", mutates_args=())
+def qpsk_bit_errors(x_hat: torch.Tensor, x_true: torch.Tensor) -> torch.Tensor:
+    """x_hat, x_true [..., 2] float32 (interleaved complex) -> float64 [2]: (bit errors, bits)."""
+    dev = _dev_check(x_hat, x_true)
+    x_hat = x_hat.contiguous().float()
+    x_true = x_true.contiguous().float()
+    N = x_hat.numel() // 2
+    out = torch.empty((2,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().cet_qpsk_bit_errors(_ptr(x_hat), _ptr(x_true), ctypes.c_void_p(out.data_ptr()),
+                                             ctypes.c_long(N), _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_qpsk_bit_errors")
+    return out
+
+
+@qpsk_bit_errors.register_fake
+def _(x_hat, x_true):
+    return x_hat.new_empty((2,), dtype=torch.float64)

@@ -155,6 +155,20 @@ int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scala
                      const float* no_dev, float* x_hat, float* no_eff, long N, int Nr, int Ns,
                      void* stream);
 
+/* ---- evaluation sums (what a rank contributes to the single all-reduce) ------------------- */
+
+/* Per prediction slot s: sums[s] = sum (truth - pred)^2, sums[P + s] = sum truth^2 over batch and
+ * the C real components (2 per antenna pair); NMSE_s = sums[s] / sums[P + s] is the quantity of
+ * HPC/python/Evaluate.py:172-177. pred, truth: device [B,P,C] float32, C % 4 == 0;
+ * sums: device double[2*P], overwritten. Accumulation in fp64. */
+int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, int P, int C,
+                  void* stream);
+
+/* Hard-decision QPSK (bit = sign of the real / imaginary part) of x_hat against x_true, both
+ * device complex64 [N] interleaved: out[0] = bit errors, out[1] = bits compared (2 N); the count
+ * behind the BER of LocalSimulations/EndtoEndtest.py:196-200. out: device double[2], overwritten. */
+int cet_qpsk_bit_errors(const float* x_hat, const float* x_true, double* out, long N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,3 +85,28 @@ def test_end_to_end_properties(model):
     b = e2e.run(model, h_hist[100:], h_future[100:], 10, 5, no=0.05, seed=1)
     assert torch.allclose(a["nmse"] + b["nmse"], sums["nmse"], rtol=1e-9)
     assert (a["bits"] + b["bits"])[1] == sums["bits"][1]
+
+
+def test_evaluation_sum_kernels_match_float64():
+    """NMSE partial sums and QPSK bit errors from the HIP reductions vs numpy float64."""
+    from channelestimationtransformer_amd import metrics
+    rng = np.random.default_rng(3)
+    for B, P, C in ((1, 5, 16), (777, 5, 16), (4096, 25, 32)):
+        t = rng.standard_normal((B, P, C)).astype(np.float32)
+        p = (t + 0.1 * rng.standard_normal((B, P, C))).astype(np.float32)
+        got = metrics.nmse_partial_sums(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+        d = t.astype(np.float64) - p.astype(np.float64)
+        want = np.stack([(d * d).sum((0, 2)), (t.astype(np.float64) ** 2).sum((0, 2))])
+        assert got.shape == (2, P) and np.allclose(got, want, rtol=1e-12)
+    # complex inputs [B, P, Nr, Nt] take the same path
+    tc = (rng.standard_normal((33, 5, 4, 2)) + 1j * rng.standard_normal((33, 5, 4, 2))).astype(np.complex64)
+    pc = (tc + 0.05).astype(np.complex64)
+    got = metrics.nmse_partial_sums(torch.from_numpy(pc).cuda(), torch.from_numpy(tc).cuda()).cpu().numpy()
+    want = np.stack([(np.abs(tc.astype(np.complex128) - pc) ** 2).sum((0, 2, 3)), (np.abs(tc.astype(np.complex128)) ** 2).sum((0, 2, 3))])
+    assert np.allclose(got, want, rtol=1e-12)
+    for N in (1, 1000, 1 << 20):
+        xt = ((2 * rng.integers(0, 2, N) - 1) + 1j * (2 * rng.integers(0, 2, N) - 1)).astype(np.complex64)
+        xh = (xt + 1.2 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
+        got = metrics.qpsk_bit_errors(torch.from_numpy(xh).cuda(), torch.from_numpy(xt).cuda()).cpu().numpy()
+        want = ((xh.real > 0) != (xt.real > 0)).sum() + ((xh.imag > 0) != (xt.imag > 0)).sum()
+        assert got[0] == want and got[1] == 2 * N
