@@ -57,3 +57,19 @@ def test_large_batch_against_checker(name, oracle):
     one = m.test_data(x[:40], 1, "cuda")
     assert torch.allclose(one, out[:40, :1], atol=0, rtol=0)
     assert m.test_data(x[:0], 5, "cuda").shape == (0, 5, 16)
+
+
+@pytest.mark.parametrize("name", ["LSTM", "RNN"])
+def test_long_horizon_rollout(name, oracle):
+    """pred_len 100: 124 recurrent steps, 100 of them closed-loop, against the CPU checker."""
+    from channelestimationtransformer_amd import synth
+    _cls, kind, F, I, H, layers = RNN_CASES[name]
+    m = build(name)
+    noisy, _ = synth.channel_histories(48, seed=9)
+    x = cet.LoadBatch(noisy[:, :25]).cuda()
+    out = m.test_data(x, 100, "cuda").cpu().numpy()
+    blob = blobs.pack_rnn(sub_dict(load_npz("rnn_ckpt.npz"), name), kind, F, I, H, layers)
+    want = oracle.rnn_rollout(kind, F, I, H, layers, blob, x.cpu().numpy(), 100)
+    assert out.shape == want.shape == (48, 100, 16)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(out - want).max() < 5e-4 * scale  # rounding differences grow along the loop
