@@ -170,6 +170,19 @@ int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scala
   return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, 1, stream);
 }
 
+int cet_lmmse_llr(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+                  float* llr, long N, int Nr, int Ns, void* stream) {
+  if (N < 0 || Nr <= 0 || Ns <= 0) return CET_ERR_INVALID_ARG;
+  if (no_mode < CET_NO_SCALAR || no_mode > CET_NO_PER_RE_RX) return CET_ERR_INVALID_ARG;
+  if (N == 0) return CET_OK;
+  if (!y || !H || !llr) return CET_ERR_INVALID_ARG;
+  if (no_mode != CET_NO_SCALAR && !no_dev) return CET_ERR_INVALID_ARG;
+  if (no_mode == CET_NO_SCALAR && !(no_scalar > 0.f)) return CET_ERR_INVALID_ARG;
+  if (Ns > Nr) return CET_ERR_UNSUPPORTED;
+  return lmmse_launch(y, H, no_mode, no_scalar, no_dev, llr, nullptr, N, Nr, Ns, 0,
+                      static_cast<hipStream_t>(stream));
+}
+
 int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, int P, int C,
                   void* stream) {
   if (!pred || !truth || !sums || B < 0 || P < 1 || C < 4 || C % 4) return CET_ERR_INVALID_ARG;

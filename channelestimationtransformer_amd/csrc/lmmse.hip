@@ -148,6 +148,20 @@ __device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS]
   }
 }
 
+// Epilogue of the LLR entry point: exact ("app") log-likelihood ratios ln(P(b=1)/P(b=0)) of
+// Gray-mapped QPSK with bit 0 on the positive axis (the convention of the reference's mapper /
+// demapper pair), from the unbiased estimate and its effective noise:
+// llr = -2 sqrt(2) Re/Im(x_hat) / no_eff. Stored in place of x_hat.
+template <int NS>
+__device__ inline void to_llr(float (&xr)[NS], float (&xi)[NS], const float (&ne)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const float k = -2.8284271247461903f * __builtin_amdgcn_rcpf(ne[s]);
+    xr[s] *= k;
+    xi[s] *= k;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Straightforward kernel: one RE per thread, operands read straight from global memory.
 // Serves every noise mode and is what the tiled kernel is cross-checked against.
@@ -181,10 +195,11 @@ __global__ __launch_bounds__(256) void lmmse_direct(const float* __restrict__ y,
   const float lam = MODE == CET_NO_SCALAR ? no_scalar : (MODE == CET_NO_PER_RE ? no_dev[n] : 1.0f);
   float xr[NS], xi[NS], ne[NS];
   lmmse_solve<NS>(g, lam, xr, xi, ne);
+  if (!no_eff) to_llr<NS>(xr, xi, ne);  // LLR entry point: x_hat receives the LLRs
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     reinterpret_cast<float2*>(x_hat)[n * NS + s] = make_float2(xr[s], xi[s]);
-    no_eff[n * NS + s] = ne[s];
+    if (no_eff) no_eff[n * NS + s] = ne[s];
   }
 }
 
@@ -343,6 +358,7 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
     if (PER_RE_NOISE) lam_reg = *reinterpret_cast<const float*>(smem + H_TILE + Y_TILE + 4 * t);
   };
 
+  const bool llr_mode = no_eff == nullptr;  // LLR entry point: one output array
   auto compute = [&](long tile) {
     Gram<NS> g;
     g.clear();
@@ -384,6 +400,7 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
     const float lam = lam_reg;
     float xr[NS], xi[NS], ne[NS];
     lmmse_solve<NS>(g, lam, xr, xi, ne);
+    if (llr_mode) to_llr<NS>(xr, xi, ne);
     const long re = tile * T + t;
     if (re < N) {
       typedef float v4f __attribute__((ext_vector_type(4)));
@@ -396,7 +413,8 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
         const v4f xv = p ? v4f{xr[S2], xi[S2], xr[S3], xi[S3]} : v4f{xr[0], xi[0], xr[NS > 1 ? 1 : 0], xi[NS > 1 ? 1 : 0]};
         const v2f nv = p ? v2f{ne[S2], ne[S3]} : v2f{ne[0], ne[NS > 1 ? 1 : 0]};
         __builtin_nontemporal_store(xv, reinterpret_cast<v4f*>(x_hat + (re * NS + 2 * p) * 2));
-        __builtin_nontemporal_store(nv, reinterpret_cast<v2f*>(no_eff + re * NS + 2 * p));
+        if (!llr_mode)
+          __builtin_nontemporal_store(nv, reinterpret_cast<v2f*>(no_eff + re * NS + 2 * p));
       } else if (p == 0) {
         float* xd = x_hat + re * NS * 2;
         float* nd = no_eff + re * NS;
@@ -410,7 +428,9 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
           for (int s = 0; s < NS; ++s)
             __builtin_nontemporal_store(v2f{xr[s], xi[s]}, reinterpret_cast<v2f*>(xd + 2 * s));
         }
-        if (NS == 4) {
+        if (llr_mode) {
+          // no_eff is not written
+        } else if (NS == 4) {
           __builtin_nontemporal_store(v4f{ne[0], ne[1], ne[2], ne[3]}, reinterpret_cast<v4f*>(nd));
         } else if (NS == 2) {
           __builtin_nontemporal_store(v2f{ne[0], ne[NS > 1 ? 1 : 0]}, reinterpret_cast<v2f*>(nd));
@@ -434,6 +454,7 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
   bool first = true;
   for (; tile < n_tiles; tile += stride) {
     if (first) wait_vmcnt<0>();
+    else if (llr_mode) wait_vmcnt<1>();  // at least one store instruction per tile there
     else wait_vmcnt<N_ST>();
     first = false;
     load_regs();

@@ -42,9 +42,10 @@ def predict_slots_recurrent(model, h_hist, pred_len):
 
 
 def qpsk(bits):
-    """bits [..., 2] in {0,1} -> (±1 ± j)/sqrt(2); bit 1 maps to the positive axis, so the
-    hard decision is `real > 0`, `imag > 0` (metrics.qpsk_bit_errors)."""
-    s = (2.0 * bits.to(torch.float32) - 1.0) * (1.0 / math.sqrt(2.0))
+    """bits [..., 2] in {0,1} -> Gray-mapped QPSK ((1 - 2 b0) + j (1 - 2 b1)) / sqrt(2): bit 0 on
+    the positive axis, the mapping of the reference's `Mapper("qam", 2)`. The hard decision
+    compares signs (metrics.qpsk_bit_errors), so BER does not depend on the convention."""
+    s = (1.0 - 2.0 * bits.to(torch.float32)) * (1.0 / math.sqrt(2.0))
     return torch.complex(s[..., 0], s[..., 1])
 
 
@@ -83,10 +84,21 @@ def equalize_slots(h_hat, y, no, err_var=0.0):
 
 
 def qpsk_llr(x_hat, no_eff):
-    """Exact ("app") bit log-likelihood ratios of Gray-mapped QPSK after unbiased LMMSE:
-    llr = 2 sqrt(2) Re/Im(x_hat) / no_eff, positive for bit 1. Returns [..., 2] float32."""
-    c = 2.0 * math.sqrt(2.0)
+    """Exact ("app") bit log-likelihood ratios of the QPSK of `qpsk` after unbiased LMMSE:
+    llr = ln(P(b=1)/P(b=0)) = -2 sqrt(2) Re/Im(x_hat) / no_eff. Returns [..., 2] float32.
+    `equalize_slots_llr` produces the same numbers inside the equalizer kernel."""
+    c = -2.0 * math.sqrt(2.0)
     return torch.stack([c * x_hat.real / no_eff, c * x_hat.imag / no_eff], dim=-1)
+
+
+def equalize_slots_llr(h_hat, y, no):
+    """`equalize_slots` followed by `qpsk_llr`, fused: returns llr [S, P, n_sym, Nt, 2]."""
+    from .lmmse import lmmse_llr
+    S, P, n_sym, Nr = y.shape
+    Nt = h_hat.shape[3]
+    N = S * P * n_sym
+    H = h_hat.unsqueeze(2).expand(S, P, n_sym, Nr, Nt).reshape(N, Nr, Nt)
+    return lmmse_llr(y.reshape(N, Nr), H, float(no)).reshape(S, P, n_sym, Nt, 2)
 
 
 def run(model, h_hist, h_future, label_len, pred_len, n_sym=14, no=0.1, seed=0, err_var=0.0,

@@ -12,10 +12,8 @@ import torch
 from . import ops  # noqa: F401
 
 
-def lmmse(y, H, no, direct=False):
-    """y [N, Nr] complex64, H [N, Nr, Ns] complex64 (CUDA); `no`: python float, tensor [N]
-    (per resource element) or tensor [N, Nr] (diagonal noise+interference covariance).
-    Returns (x_hat [N, Ns] complex64, no_eff [N, Ns] float32)."""
+def _prepare(y, H, no):
+    """Validates the flat operands; returns (y, H, no tensor, scalar no, noise mode)."""
     if not (torch.is_complex(y) and torch.is_complex(H)):
         raise RuntimeError("y and H must be complex tensors")
     y = y.to(torch.complex64).contiguous()
@@ -34,9 +32,26 @@ def lmmse(y, H, no, direct=False):
     else:
         mode, no_s = 0, float(no)
         no_t = torch.empty(0, dtype=torch.float32, device=y.device)
+    return y, H, no_t, no_s, mode
+
+
+def lmmse(y, H, no, direct=False):
+    """y [N, Nr] complex64, H [N, Nr, Ns] complex64 (CUDA); `no`: python float, tensor [N]
+    (per resource element) or tensor [N, Nr] (diagonal noise+interference covariance).
+    Returns (x_hat [N, Ns] complex64, no_eff [N, Ns] float32)."""
+    y, H, no_t, no_s, mode = _prepare(y, H, no)
     x, ne = torch.ops.cet.lmmse(torch.view_as_real(y), torch.view_as_real(H), no_t, no_s, mode,
                                 bool(direct))
     return torch.view_as_complex(x), ne
+
+
+def lmmse_llr(y, H, no):
+    """Equalizer and QPSK demapper in one kernel: same operands as `lmmse`, returns the bit
+    log-likelihood ratios [N, Ns, 2] float32, ln(P(b=1)/P(b=0)) with bit 0 on the positive axis
+    (what a `Demapper("app", "qam", 2)` makes of `lmmse`'s outputs, HPC/python/EvaluateE2E.py:
+    292-319)."""
+    y, H, no_t, no_s, mode = _prepare(y, H, no)
+    return torch.ops.cet.lmmse_llr(torch.view_as_real(y), torch.view_as_real(H), no_t, no_s, mode)
 
 
 class StreamManagement:

@@ -134,3 +134,26 @@ def qpsk_bit_errors(x_hat: torch.Tensor, x_true: torch.Tensor) -> torch.Tensor:
 @qpsk_bit_errors.register_fake
 def _(x_hat, x_true):
     return x_hat.new_empty((2,), dtype=torch.float64)
+
+
+@torch.library.custom_op("cet::lmmse_llr", mutates_args=())
+def lmmse_llr(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: float,
+              no_mode: int) -> torch.Tensor:
+    """y [N,Nr,2], H [N,Nr,Ns,2] float32 -> QPSK bit LLRs [N,Ns,2] (equalizer + demapper fused)."""
+    dev = _dev_check(y, H)
+    y = y.contiguous()
+    H = H.contiguous()
+    N, Nr, Ns = H.shape[0], H.shape[1], H.shape[2]
+    llr = torch.empty((N, Ns, 2), dtype=torch.float32, device=dev)
+    no_dev = no.contiguous() if no_mode != 0 else None
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().cet_lmmse_llr(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar),
+                                       _ptr(no_dev), _ptr(llr), ctypes.c_long(N), Nr, Ns,
+                                       _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_lmmse_llr")
+    return llr
+
+
+@lmmse_llr.register_fake
+def _(y, H, no, no_scalar, no_mode):
+    return y.new_empty((H.shape[0], H.shape[2], 2))

@@ -155,6 +155,15 @@ int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scala
                      const float* no_dev, float* x_hat, float* no_eff, long N, int Nr, int Ns,
                      void* stream);
 
+/* cet_lmmse with the QPSK demapper fused into its epilogue: instead of (x_hat, no_eff) the kernel
+ * writes llr [N,Ns,2] float32, the exact bit log-likelihood ratios ln(P(b=1)/P(b=0)) =
+ * -2 sqrt(2) Re/Im(x_hat) / no_eff of Gray-mapped QPSK with bit 0 on the positive axis (the
+ * "app" demapper that follows the equalizer in the reference's receive chain,
+ * HPC/python/EvaluateE2E.py:292-319); 16 B less HBM traffic per stream than equalizing and
+ * demapping in two passes. Same argument meaning and support as cet_lmmse. */
+int cet_lmmse_llr(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
+                  float* llr, long N, int Nr, int Ns, void* stream);
+
 /* ---- evaluation sums (what a rank contributes to the single all-reduce) ------------------- */
 
 /* Per prediction slot s: sums[s] = sum (truth - pred)^2, sums[P + s] = sum truth^2 over batch and

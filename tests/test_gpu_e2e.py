@@ -63,7 +63,14 @@ def test_equalization_step_matches_checker(oracle):
         assert np.abs(no_eff.reshape(-1, Nt).cpu().numpy() / nw - 1).max() < 1e-3
     llr = e2e.qpsk_llr(x_hat, no_eff)
     assert llr.shape == (S, P, n_sym, Nt, 2)
-    assert torch.equal(llr[..., 0] > 0, x_hat.real > 0)
+    assert torch.equal(llr[..., 0] < 0, x_hat.real > 0)  # llr = ln P(b=1)/P(b=0), bit 0 positive
+    # the fused equalizer + demapper kernel gives the same LLRs as the two-step path
+    x2, ne2 = e2e.equalize_slots(h_hat, y, 0.05)
+    fused = e2e.equalize_slots_llr(h_hat, y, 0.05)
+    two_step = e2e.qpsk_llr(x2, ne2)
+    assert torch.allclose(fused, two_step, rtol=1e-5, atol=1e-5)
+    # ... and they decide the transmitted bits: a positive LLR means bit 1 = negative axis
+    assert ((fused[..., 0] > 0) == (x.real < 0)).float().mean() > 0.99
 
 
 def test_end_to_end_properties(model):

@@ -119,3 +119,21 @@ def test_equalizer_object_on_the_reference_geometry(oracle):
     x2, ne2 = equ([torch.from_numpy(y).cuda(), torch.from_numpy(h).cuda(), torch.tensor(ev), no])
     wx2, wne2 = oracle.lmmse(yd, hd, np.full((yd.shape[0], 4), no + 2 * ev, np.float32))
     assert close(x2.cpu().numpy(), wx2.reshape(b, 832, 2).transpose(0, 2, 1)[:, None])
+
+
+@pytest.mark.parametrize("Nr,Ns", [(16, 4), (8, 2), (4, 2), (4, 1)])
+def test_fused_llr_epilogue(Nr, Ns, oracle):
+    """cet_lmmse_llr = -2 sqrt(2) x_hat / no_eff of the checker, per noise mode (the per-antenna
+    mode runs the direct kernel, the others the tiled one), ragged N."""
+    N = 4099
+    y, H, _ = synth.lmmse_problem(N, Nr, Ns, 0.2, seed=11)
+    yt, Ht = torch.from_numpy(y).cuda(), torch.from_numpy(H).cuda()
+    rng = np.random.default_rng(1)
+    for no in (0.2, rng.uniform(0.05, 0.5, N).astype(np.float32),
+               rng.uniform(0.05, 0.5, (N, Nr)).astype(np.float32)):
+        wx, wne = oracle.lmmse(y, H, no)
+        want = -2.0 * np.sqrt(2.0) * np.stack([wx.real, wx.imag], -1) / wne[..., None]
+        no_t = no if isinstance(no, float) else torch.from_numpy(no).cuda()
+        got = cet.lmmse_llr(yt, Ht, no_t).cpu().numpy()
+        assert got.shape == (N, Ns, 2)
+        assert np.abs(got - want).max() < 2e-4 * np.abs(want).max()
