@@ -1570,7 +1570,20 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   // on every call so that a test can switch between the two.
   const char* force = getenv("CET_INFORMER_KERNEL");
   const bool force_one = force && force[0] == 'o', force_wg = force && force[0] == 'w';
-  const size_t wg_wave_bytes = (size_t)(2 * R + 2) * LDW * sizeof(float);
+  // Packed tiles are whole 16-row tiles: K | V regions of at least 16 rows, and the packed
+  // conv staging of 16 + 32 rows. Where that does not fit, the workgroup kernel runs unpacked.
+  int R_wg = R, wg_rows = 2 * R + 2;
+  if (a.n_pack0 < a.n_ops) {
+    const int Rp = R < 16 ? 16 : R;
+    const int rows_p = 2 * Rp + 2 < 48 ? 48 : 2 * Rp + 2;
+    if (2 * WBLK * sizeof(float) + WG_WAVES * (size_t)rows_p * LDW * sizeof(float) <= 160 * 1024) {
+      R_wg = Rp;
+      wg_rows = rows_p;
+    } else {
+      a.n_pack0 = a.n_ops;
+    }
+  }
+  const size_t wg_wave_bytes = (size_t)wg_rows * LDW * sizeof(float);
   const size_t wg_lds = 2 * WBLK * sizeof(float) + WG_WAVES * wg_wave_bytes;
   // The workgroup kernel fills a CU with 8 sequences; below about 5 sequences per CU the
   // one-wave kernel, which spreads single waves over all CUs, finishes sooner.
@@ -1591,6 +1604,7 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   const bool d2 = Ld > 16, m2 = a.mem_rows > 16;
   if (wg) {
     a.wave_lds_floats = (int)(wg_wave_bytes / sizeof(float));
+    a.region_rows = R_wg;
     const dim3 grid((unsigned)((B + WG_WAVES - 1) / WG_WAVES)), block(64 * WG_WAVES);
 #define CET_LAUNCH_WG(RD_, RM_)                                                                  \
   do {                                                                                           \

@@ -1,0 +1,72 @@
+"""Randomized configurations of the Transformer predictor against the CPU checker: every debug
+stage, every attention map and the prediction, on each kernel path (one wave per sequence,
+8-wave workgroups with and without packed tiles). Weights and BatchNorm statistics are random;
+the checker itself is pinned to the reference by tests/test_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+import channelestimationtransformer_amd as cet
+from channelestimationtransformer_amd import blobs
+from test_gpu_informer import TOL_ATTN, TOL_PRED, TOL_STAGE, run_taps
+
+pytestmark = pytest.mark.gpu
+
+# (class, enc_in, seq_len, label_len, pred_len, e_layers, d_layers, activation, distil, batch)
+CONFIGS = [
+    ("InformerStack", 16, 25, 10, 5, 4, 3, "gelu", True, 13),   # the default shape, ragged batch
+    ("InformerStack", 16, 30, 12, 4, 5, 1, "relu", True, 9),    # longest input, three encoders
+    ("InformerStack", 32, 16, 8, 8, 3, 2, "gelu", True, 8),     # one-tile input, 32 channels
+    ("InformerStack", 16, 24, 20, 12, 4, 2, "gelu", True, 5),   # 32 decoder rows (two tiles)
+    ("Informer", 16, 8, 4, 2, 3, 1, "gelu", True, 20),          # short from the start
+    ("Informer", 16, 28, 6, 3, 4, 2, "relu", True, 12),
+    ("Informer", 32, 20, 10, 10, 2, 3, "gelu", False, 7),       # no distilling: 20 rows throughout
+    ("Informer", 16, 7, 3, 1, 1, 1, "gelu", True, 33),          # single layer, 7 rows
+    ("InformerStack", 16, 12, 6, 6, 3, 1, "gelu", False, 11),   # stack without distilling
+    ("InformerStack", 16, 29, 1, 2, 6, 1, "gelu", True, 6),     # deepest stack the planner takes
+    ("InformerStack", 16, 14, 7, 7, 4, 2, "gelu", False, 10),   # slice 14 -> 7, memory of 21 rows
+    ("InformerStack", 32, 16, 3, 13, 5, 2, "relu", True, 17),   # packed from the third step on
+]
+
+
+def randomized(cls, enc_in, seq_len, label_len, pred_len, e_layers, d_layers, act, distil, seed):
+    g = torch.Generator().manual_seed(seed)
+    m = getattr(cet, cls)(enc_in, enc_in, enc_in, seq_len, label_len, pred_len, 5, 64, 8, e_layers,
+                          d_layers, 64, 0.0, "full", "fixed", act, True, distil)
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if k.endswith("position_embedding.pe") or k.endswith("num_batches_tracked"):
+            continue
+        if k.endswith("running_var"):
+            v.copy_(torch.rand(v.shape, generator=g) * 1.5 + 0.25)
+        elif k.endswith("norm.weight") or ".norm1.weight" in k or ".norm2.weight" in k or ".norm3.weight" in k:
+            v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=g))
+        elif v.dim() >= 2:
+            v.copy_(torch.randn(v.shape, generator=g) * (0.9 / np.sqrt(v[0].numel())))
+        else:
+            v.copy_(0.1 * torch.randn(v.shape, generator=g))
+    m.load_state_dict(sd)
+    return m.eval(), {k: v.numpy() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("kernel", ["one_wave", "workgroup", "workgroup_unpacked"])
+@pytest.mark.parametrize("case", range(len(CONFIGS)))
+def test_random_configuration(case, kernel, oracle, monkeypatch):
+    monkeypatch.setenv("CET_INFORMER_KERNEL", "one_wave" if kernel == "one_wave" else "workgroup")
+    monkeypatch.setenv("CET_INFORMER_PACK", "0" if kernel.endswith("unpacked") else "1")
+    cls, enc_in, seq_len, label_len, pred_len, e_layers, d_layers, act, distil, B = CONFIGS[case]
+    m, sd = randomized(cls, enc_in, seq_len, label_len, pred_len, e_layers, d_layers, act, distil, case)
+    cfg = m._cfg
+    rng = np.random.default_rng(100 + case)
+    x_enc = rng.standard_normal((B, seq_len, enc_in)).astype(np.float32)
+    x_dec = np.concatenate([x_enc[:, seq_len - label_len:], np.zeros((B, pred_len, enc_in), np.float32)], 1)
+    want, want_attn, want_taps = oracle.informer_forward(cfg, blobs.pack_informer(sd, cfg), x_enc, x_dec,
+                                                         want_attn=True, want_taps=True)
+    pred, taps, attn = run_taps(m, x_enc, x_dec)
+    rows = oracle.tap_rows(cfg)
+    for i, (t, w) in enumerate(zip(oracle.split_taps(taps, rows, B, 64), want_taps)):
+        err = np.abs(t - w).max()
+        assert err < TOL_STAGE, f"stage {i} (rows {rows[i]}): {err}"
+    for i, (a, w) in enumerate(zip(oracle.split_attn(attn, oracle.attn_lengths(cfg), B, 8), want_attn)):
+        assert np.abs(a - w).max() < TOL_ATTN, f"attention map {i}"
+    assert np.abs(pred - want).max() < TOL_PRED
