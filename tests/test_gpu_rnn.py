@@ -73,3 +73,23 @@ def test_long_horizon_rollout(name, oracle):
     assert out.shape == want.shape == (48, 100, 16)
     scale = max(1.0, float(np.abs(want).max()))
     assert np.abs(out - want).max() < 5e-4 * scale  # rounding differences grow along the loop
+
+
+SWEEP = [(cls, F, I, H, layers) for cls in ("RNN", "GRU", "LSTM")
+         for (F, I, H, layers) in ((16, 16, 128, 1), (32, 32, 256, 3), (8, 24, 128, 2), (16, 32, 256, 1))]
+
+
+@pytest.mark.parametrize("cls,F,I,H,layers", SWEEP)
+def test_random_shapes_against_checker(cls, F, I, H, layers, oracle):
+    """Every supported (features, input, hidden, layers) corner with random weights, a ragged
+    batch and a rollout that is half teacher-forced, half closed-loop."""
+    kind = {"RNN": 0, "GRU": 1, "LSTM": 2}[cls]
+    torch.manual_seed(F + I + H + layers + kind)
+    m = getattr(cet, cls)(F, I, H, layers).eval()
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(H + layers)
+    x = rng.standard_normal((45, 12, F)).astype(np.float32)
+    out = m.test_data(torch.from_numpy(x).cuda(), 9, "cuda").cpu().numpy()
+    want = oracle.rnn_rollout(kind, F, I, H, layers, blobs.pack_rnn(sd, kind, F, I, H, layers), x, 9)
+    assert out.shape == want.shape == (45, 9, F)
+    assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
