@@ -183,6 +183,15 @@ int cet_lmmse_llr(const float* y, const float* H, int no_mode, float no_scalar, 
                       static_cast<hipStream_t>(stream));
 }
 
+int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float* pabs2inv,
+              float no, float* h_hat, float* err_var, long planes, int plane, int T, void* stream) {
+  if (planes < 0 || plane < 1 || T < 1 || !(no >= 0.f)) return CET_ERR_INVALID_ARG;
+  if (planes == 0) return CET_OK;
+  if (!y || !src || !pinv || !pabs2inv || !h_hat || !err_var) return CET_ERR_INVALID_ARG;
+  return ls_nn_launch(y, src, pinv, pabs2inv, no, h_hat, err_var, planes, plane, T,
+                      static_cast<hipStream_t>(stream));
+}
+
 int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, int P, int C,
                   void* stream) {
   if (!pred || !truth || !sums || B < 0 || P < 1 || C < 4 || C % 4) return CET_ERR_INVALID_ARG;

@@ -28,6 +28,8 @@ int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, c
                  float* x_hat, float* no_eff, long N, int Nr, int Ns, int variant,
                  hipStream_t stream);
 
+int ls_nn_launch(const float* y, const int* src, const float* pinv, const float* pabs2inv, float no,
+                 float* h_hat, float* err_var, long planes, int plane, int T, hipStream_t stream);
 int nmse_sums_launch(const float* pred, const float* truth, double* sums, long B, int P, int C,
                      hipStream_t stream);
 int qpsk_errors_launch(const float* x_hat, const float* x_true, double* out, long N,

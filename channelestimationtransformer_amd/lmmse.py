@@ -98,6 +98,32 @@ class ResourceGrid:
         self.data_symbol_ind = np.array([s for s in range(self.num_ofdm_symbols) if s not in pil])
         self.num_data_symbols = len(self.data_symbol_ind) * self.num_effective_subcarriers
         self.bandwidth = self.fft_size * self.subcarrier_spacing
+        self.pilots = self._kronecker_pilots(seed=0) if pil else None
+
+    def _kronecker_pilots(self, seed):
+        """Pilots of the 'kronecker' pattern, complex64 [num_tx, num_streams_per_tx,
+        num_pilot_symbols, num_effective_subcarriers]: on every pilot OFDM symbol stream k (of
+        K = num_tx * num_streams_per_tx) occupies the effective subcarriers k, k + K, ... and is
+        silent on the others; the occupied positions carry QPSK symbols scaled so that a
+        stream's pilots have unit mean energy over all pilot positions (amplitude sqrt(K)).
+        The symbols come from numpy's generator (Sionna draws its own from TensorFlow's);
+        `set_pilots` installs other values."""
+        K = self.num_tx * self.num_streams_per_tx
+        n_p, n_sc = len(self.pilot_ofdm_symbol_indices), self.num_effective_subcarriers
+        rng = np.random.default_rng(seed)
+        bits = rng.integers(0, 2, (K, n_p, n_sc, 2))
+        qpsk = ((1 - 2 * bits[..., 0]) + 1j * (1 - 2 * bits[..., 1])) / np.sqrt(2.0)
+        mask = (np.arange(n_sc)[None, :] % K) == np.arange(K)[:, None]
+        p = qpsk * mask[:, None, :] * np.sqrt(K)
+        return p.reshape(self.num_tx, self.num_streams_per_tx, n_p, n_sc).astype(np.complex64)
+
+    def set_pilots(self, pilots):
+        pilots = np.asarray(pilots, dtype=np.complex64)
+        want = (self.num_tx, self.num_streams_per_tx, len(self.pilot_ofdm_symbol_indices),
+                self.num_effective_subcarriers)
+        if pilots.shape != want:
+            raise ValueError(f"pilots must have shape {want}")
+        self.pilots = pilots
 
 
 class LMMSEEqualizer:
@@ -147,3 +173,64 @@ class LMMSEEqualizer:
         x = x.reshape(b, len(sym) * len(sc), ntx, nst).permute(0, 2, 3, 1).contiguous()
         ne = ne.reshape(b, len(sym) * len(sc), ntx, nst).permute(0, 2, 3, 1).contiguous()
         return x, ne
+
+
+class LSChannelEstimator:
+    """`LSChannelEstimator(rg, interpolation_type="nn")([y, no]) -> (h_hat, err_var)`, the
+    estimator in front of the equalizer on the reference's estimated-CSI branch
+    (LocalSimulations/EndtoEndtest.py:130,184).
+
+    y      [batch, num_rx=1, num_rx_ant, num_ofdm_symbols, fft_size]                  complex
+    h_hat  [batch, 1, num_rx_ant, num_tx, num_streams_per_tx, num_ofdm_symbols, n_eff] complex
+    err_var same shape, float32
+    At a pilot position of stream k: h = y / p, err_var = no / |p|^2. Every other resource
+    element takes the values of the stream's nearest pilot, nearest by |symbol distance| +
+    |subcarrier distance| (effective subcarriers), the first one in (symbol, subcarrier) order
+    among equals. The geometry is resolved once on the host into a gather table; the kernel
+    (csrc/lsest.hip) gathers and scales."""
+
+    def __init__(self, resource_grid, interpolation_type="nn"):
+        if interpolation_type != "nn":
+            raise NotImplementedError("only nearest-neighbour interpolation is implemented")
+        if resource_grid.pilots is None:
+            raise ValueError("the resource grid carries no pilots")
+        self.rg = resource_grid
+        self._tables = self._build_tables()
+        self._dev = {}
+
+    def _build_tables(self):
+        rg = self.rg
+        K = rg.num_tx * rg.num_streams_per_tx
+        n_sym, n_sc = rg.num_ofdm_symbols, rg.num_effective_subcarriers
+        pil = rg.pilots.reshape(K, len(rg.pilot_ofdm_symbol_indices), n_sc)
+        src = np.empty((K, n_sym, n_sc), np.int32)
+        pinv = np.empty((K, n_sym, n_sc), np.complex64)
+        s_idx = np.arange(n_sym)[:, None, None]
+        f_idx = np.arange(n_sc)[None, :, None]
+        for k in range(K):
+            pp, pf = np.nonzero(pil[k])                       # (pilot symbol, subcarrier) order
+            ps = np.asarray(rg.pilot_ofdm_symbol_indices)[pp]
+            dist = np.abs(s_idx - ps[None, None, :]) + np.abs(f_idx - pf[None, None, :])
+            near = dist.argmin(-1)                             # first minimum
+            src[k] = ps[near] * rg.fft_size + rg.effective_subcarrier_ind[pf[near]]
+            pinv[k] = 1.0 / pil[k][pp[near], pf[near]]
+        return src.reshape(-1), pinv.reshape(-1), (np.abs(pinv) ** 2).astype(np.float32).reshape(-1)
+
+    def __call__(self, inputs):
+        y, no = inputs
+        rg = self.rg
+        if y.dim() != 5 or y.shape[1] != 1 or y.shape[3] != rg.num_ofdm_symbols or y.shape[4] != rg.fft_size:
+            raise RuntimeError("expected y [b, 1, ant, num_ofdm_symbols, fft_size]")
+        dev = y.device
+        if dev not in self._dev:
+            src, pinv, p2 = self._tables
+            self._dev[dev] = (torch.from_numpy(src).to(dev),
+                              torch.view_as_real(torch.from_numpy(pinv)).contiguous().to(dev),
+                              torch.from_numpy(p2).to(dev))
+        src, pinv, p2 = self._dev[dev]
+        b, _, ant = y.shape[:3]
+        yr = torch.view_as_real(y.to(torch.complex64).contiguous()).reshape(b * ant, -1, 2)
+        h, ev = torch.ops.cet.ls_nn(yr, src, pinv, p2, float(no))
+        shape = (b, 1, ant, rg.num_tx, rg.num_streams_per_tx, rg.num_ofdm_symbols,
+                 rg.num_effective_subcarriers)
+        return torch.view_as_complex(h).reshape(shape), ev.reshape(shape)

@@ -157,3 +157,27 @@ def lmmse_llr(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: flo
 @lmmse_llr.register_fake
 def _(y, H, no, no_scalar, no_mode):
     return y.new_empty((H.shape[0], H.shape[2], 2))
+
+
+@torch.library.custom_op("cet::ls_nn", mutates_args=())
+def ls_nn(y: torch.Tensor, src: torch.Tensor, pinv: torch.Tensor, pabs2inv: torch.Tensor,
+          no: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """y [planes, plane, 2] float32 (interleaved complex), tables of T entries ->
+    h_hat [planes, T, 2], err_var [planes, T]."""
+    dev = _dev_check(y, src, pinv, pabs2inv)
+    y = y.contiguous()
+    planes, plane = y.shape[0], y.shape[1]
+    T = src.numel()
+    h_hat = torch.empty((planes, T, 2), dtype=torch.float32, device=dev)
+    err_var = torch.empty((planes, T), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().cet_ls_nn(_ptr(y), _ptr(src), _ptr(pinv), _ptr(pabs2inv), ctypes.c_float(no),
+                                   _ptr(h_hat), _ptr(err_var), ctypes.c_long(planes), plane, T,
+                                   _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_ls_nn")
+    return h_hat, err_var
+
+
+@ls_nn.register_fake
+def _(y, src, pinv, pabs2inv, no):
+    return y.new_empty((y.shape[0], src.numel(), 2)), y.new_empty((y.shape[0], src.numel()))

@@ -164,6 +164,20 @@ int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scala
 int cet_lmmse_llr(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
                   float* llr, long N, int Nr, int Ns, void* stream);
 
+/* ---- LS channel estimate with nearest-neighbour interpolation ------------------------------ */
+
+/* Per-stream least-squares estimate at the pilots, spread over the resource grid by nearest
+ * pilot: stands in for `LSChannelEstimator(rg, interpolation_type="nn")([y, no])`
+ * (LocalSimulations/EndtoEndtest.py:130,184), with the pilot geometry resolved by the caller
+ * into a table of T = streams * symbols * effective subcarriers entries:
+ *   src[t]      index of the nearest pilot's observation inside one receive antenna's
+ *               [symbols * fft_size] plane of y,
+ *   pinv[t]     1 / pilot (complex, interleaved),   pabs2inv[t] = 1 / |pilot|^2.
+ * y: device [planes, plane] complex64 (planes = batch * receive antennas);
+ * h_hat: device [planes, T] complex64, err_var: device [planes, T] float32 = no / |pilot|^2. */
+int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float* pabs2inv,
+              float no, float* h_hat, float* err_var, long planes, int plane, int T, void* stream);
+
 /* ---- evaluation sums (what a rank contributes to the single all-reduce) ------------------- */
 
 /* Per prediction slot s: sums[s] = sum (truth - pred)^2, sums[P + s] = sum truth^2 over batch and

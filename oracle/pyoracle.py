@@ -149,3 +149,32 @@ def lmmse_numpy(y, H, no):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def ls_nn_numpy(y, pilots, pilot_symbols, eff_sc, no):
+    """Brute-force float64 statement of the LS channel estimate with nearest-neighbour
+    interpolation (the checker of csrc/lsest.hip; no reference vector exists for it: Sionna, whose
+    `LSChannelEstimator(rg, interpolation_type="nn")` it stands in for at
+    LocalSimulations/EndtoEndtest.py:130,184, is absent -> parity unpinned).
+    y [b, ant, n_sym, fft] complex; pilots [K, n_pilot_sym, n_eff] complex (0 = no pilot);
+    pilot_symbols [n_pilot_sym] OFDM symbol indices; eff_sc [n_eff] fft indices.
+    -> h_hat [b, ant, K, n_sym, n_eff] complex128, err_var same shape float64."""
+    y = np.asarray(y, np.complex128)
+    b, ant, n_sym, _ = y.shape
+    K, _, n_eff = pilots.shape
+    h = np.zeros((b, ant, K, n_sym, n_eff), np.complex128)
+    ev = np.zeros((b, ant, K, n_sym, n_eff))
+    for k in range(K):
+        cand = [(ip, f) for ip in range(len(pilot_symbols)) for f in range(n_eff) if pilots[k, ip, f] != 0]
+        for s in range(n_sym):
+            for f in range(n_eff):
+                best, bd = None, None
+                for ip, pf in cand:
+                    d = abs(s - int(pilot_symbols[ip])) + abs(f - pf)
+                    if bd is None or d < bd:
+                        best, bd = (ip, pf), d
+                ip, pf = best
+                p = complex(pilots[k, ip, pf])
+                h[:, :, k, s, f] = y[:, :, int(pilot_symbols[ip]), int(eff_sc[pf])] / p
+                ev[:, :, k, s, f] = no / abs(p) ** 2
+    return h, ev

@@ -137,3 +137,35 @@ def test_fused_llr_epilogue(Nr, Ns, oracle):
         got = cet.lmmse_llr(yt, Ht, no_t).cpu().numpy()
         assert got.shape == (N, Ns, 2)
         assert np.abs(got - want).max() < 2e-4 * np.abs(want).max()
+
+
+def test_ls_estimator_nearest_neighbour(oracle):
+    """LS estimate + nearest-neighbour interpolation against the brute-force statement, on the
+    reference's grid (14 symbols, fft 76, guards 5/6, DC nulled, pilots on symbol 0; here two
+    pilot symbols to exercise the time axis) and on the estimator -> equalizer chain."""
+    rg = cet.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=1,
+                          num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                          dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    assert rg.num_effective_subcarriers == 64 and rg.pilots.shape == (1, 2, 2, 64)
+    assert np.allclose((np.abs(rg.pilots) ** 2).mean(-1), 1.0)
+    est = cet.LSChannelEstimator(rg, interpolation_type="nn")
+    rng = np.random.default_rng(4)
+    b, ant = 3, 4
+    y = (rng.standard_normal((b, 1, ant, 14, 76)) + 1j * rng.standard_normal((b, 1, ant, 14, 76))).astype(np.complex64)
+    h_hat, err_var = est([torch.from_numpy(y).cuda(), 0.3])
+    assert h_hat.shape == err_var.shape == (b, 1, ant, 1, 2, 14, 64)
+    wh, wev = oracle.ls_nn_numpy(y[:, 0], rg.pilots.reshape(2, 2, 64), rg.pilot_ofdm_symbol_indices,
+                                 rg.effective_subcarrier_ind, 0.3)
+    assert np.abs(h_hat.cpu().numpy().reshape(wh.shape) - wh).max() < 1e-5
+    assert np.abs(err_var.cpu().numpy().reshape(wev.shape) - wev).max() < 1e-6
+    # a flat channel observed without noise through the pilots is recovered exactly everywhere
+    H = (rng.standard_normal((b, ant, 2)) + 1j * rng.standard_normal((b, ant, 2))).astype(np.complex64)
+    grid = np.zeros((b, 1, ant, 14, 76), np.complex64)
+    for ip, s in enumerate(rg.pilot_ofdm_symbol_indices):
+        grid[:, 0, :, s, rg.effective_subcarrier_ind] = np.einsum("bak,kf->fba", H, rg.pilots[0, :, ip, :])
+    h2, _ = est([torch.from_numpy(grid).cuda(), 0.0])
+    assert np.abs(h2.cpu().numpy() - H[:, None, :, None, :, None, None]).max() < 1e-5
+    # estimator output feeds the equalizer object unchanged
+    x_hat, no_eff = cet.LMMSEEqualizer(rg, cet.StreamManagement(np.array([[1]]), 2))(
+        [torch.from_numpy(y).cuda(), h_hat, err_var, 0.3])
+    assert x_hat.shape == (b, 1, 2, 12 * 64) and torch.isfinite(no_eff).all()
