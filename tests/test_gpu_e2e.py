@@ -117,3 +117,13 @@ def test_evaluation_sum_kernels_match_float64():
         got = metrics.qpsk_bit_errors(torch.from_numpy(xh).cuda(), torch.from_numpy(xt).cuda()).cpu().numpy()
         want = ((xh.real > 0) != (xt.real > 0)).sum() + ((xh.imag > 0) != (xt.imag > 0)).sum()
         assert got[0] == want and got[1] == 2 * N
+
+
+def test_device_channel_generator():
+    noisy, clean = synth.channel_histories_device(2048, "cuda:0", seed=3)
+    assert noisy.shape == clean.shape == (2048, 30, 4, 2) and noisy.dtype == torch.complex64
+    assert abs(float((clean.abs() ** 2).mean()) - 1.0) < 1e-3            # unit mean power
+    snr = float((clean.abs() ** 2).mean() / ((noisy - clean).abs() ** 2).mean())
+    assert abs(10 * np.log10(snr) - 20.0) < 0.2                          # 20 dB by default
+    again, _ = synth.channel_histories_device(2048, "cuda:0", seed=3)
+    assert torch.equal(noisy, again)                                     # seeded
