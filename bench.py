@@ -272,6 +272,18 @@ def main():
                                    "hbm_GBps": 688.0 * N / d3 / 1e9,
                                    "hbm_frac": 688.0 * N / d3 / 1e9 / PEAK_HBM_GBS}
             del y, H
+            # the reference-sized equalizer shapes (4 x 2 of EndtoEndtest.py, 8 x 4)
+            for (nr, ns) in ((8, 4), (4, 2)):
+                Nv = 1 << 24
+                yv, Hv, _xs = lmmse_inputs(Nv, nr, ns, 0.1, dev, 0)
+                def step3b():
+                    cet.lmmse(yv, Hv, 0.1)
+                _w, dv = timed_loop(step3b, 10, 2, False, dev)
+                bpr = LMMSE_BYTES[(nr, ns)]
+                extra[f"lmmse_{nr}x{ns}"] = {"REs_per_s": Nv / dv, "kernel_ms": dv * 1e3, "N": Nv,
+                                             "hbm_GBps": bpr * Nv / dv / 1e9,
+                                             "hbm_frac": bpr * Nv / dv / 1e9 / PEAK_HBM_GBS}
+                del yv, Hv
             for kind in ("lstm", "gru", "rnn"):
                 rm, _sd = make_rnn(kind)
                 nb, _ = synth.channel_histories(8192, seed=1)
