@@ -11,13 +11,17 @@
 // k-step (mt, i) of the next product: Linear -> GELU -> Linear -> +residual -> LayerNorm
 // chains run register to register, and every weight matrix is read in its PyTorch row-major
 // layout with one 16-byte load per lane and k-block (no packing).
-// LDS (26 KB per wave) only holds what needs a cross-row view: Q, K, V of the attention at
-// hand, and the staging rows of the circular convolutions / max-pool.
+// LDS only holds what needs a cross-row view: K and V (and, in the one-wave kernel, Q) of the
+// attention at hand, and the staging rows of the circular convolutions / max-pool.
 // Attention: S^T = K Q^T per head on MFMA (A = K rows, B = Q rows, k = the 8 head features),
 // which leaves every query's scores in one lane column: softmax is 8 in-lane values plus two
 // cross-lane steps. The normalised probabilities are then the B operand of the P*V product
 // as they stand; two heads share one 16-feature output tile by zeroing the other head's
 // rows of the V^T operand.
+// Two launch shapes of this code (informer_kernel<.., WG>): one wave per workgroup with the
+// weights read from global memory, and workgroups of 8 waves (8 sequences) that walk the
+// network in step, share every weight block through LDS ("weight staging") and, once the
+// sequences are short, carry two sequences in one tile ("two sequences in one tile").
 // All arithmetic is fp32 (MFMA f32 = exact fmaf chains). exp is 2^(x log2 e) on the hardware
 // exp2 (1 ulp), reciprocals and 1/sqrt are the 1-ulp hardware forms, erf is a 1.5e-7 fit.
 #include <cstdio>
