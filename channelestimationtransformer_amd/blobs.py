@@ -60,6 +60,7 @@ def pack_informer(sd, cfg):
         parts.append(a.reshape(-1))
 
     D, F = cfg.d_model, cfg.d_ff
+    HE = (D // cfg.n_heads) * cfg.n_heads  # d_keys * n_heads (attn.py:121-138)
     for emb, cin, L in (("enc_embedding", cfg.enc_in, cfg.seq_len),
                         ("dec_embedding", cfg.dec_in, cfg.label_len + cfg.pred_len)):
         put(f"{emb}.value_embedding.tokenConv.weight", (D, cin, 3))
@@ -68,9 +69,11 @@ def pack_informer(sd, cfg):
         parts.append(np.ascontiguousarray(pe.reshape(-1, D)[:L]).reshape(-1))
 
     def put_attn(prefix):
-        for proj in ("query", "key", "value", "out"):
-            put(f"{prefix}.{proj}_projection.weight", (D, D))
-            put(f"{prefix}.{proj}_projection.bias", (D,))
+        for proj in ("query", "key", "value"):
+            put(f"{prefix}.{proj}_projection.weight", (HE, D))
+            put(f"{prefix}.{proj}_projection.bias", (HE,))
+        put(f"{prefix}.out_projection.weight", (D, HE))
+        put(f"{prefix}.out_projection.bias", (D,))
 
     def put_ffn(prefix):
         # Conv1d(kernel_size=1) weights are [out, in, 1]
@@ -118,7 +121,8 @@ def informer_blob_len(cfg):
     D, F = cfg.d_model, cfg.d_ff
     n = D * cfg.enc_in * 3 + D + cfg.seq_len * D
     n += D * cfg.dec_in * 3 + D + (cfg.label_len + cfg.pred_len) * D
-    attn = 4 * (D * D + D)
+    HE = (D // cfg.n_heads) * cfg.n_heads
+    attn = 3 * (HE * D + HE) + D * HE + D
     ffn = F * D + F + D * F + D
     for el in encoder_depths(cfg.e_layers, cfg.stack):
         n += el * (attn + ffn + 4 * D)

@@ -24,6 +24,7 @@
 // sequences are short, carry two sequences in one tile ("two sequences in one tile").
 // All arithmetic is fp32 (MFMA f32 = exact fmaf chains). exp is 2^(x log2 e) on the hardware
 // exp2 (1 ulp), reciprocals and 1/sqrt are the 1-ulp hardware forms, erf is a 1.5e-7 fit.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <new>
@@ -82,6 +83,8 @@ struct KArgs {
   int n_blk;
   int wave_lds_floats;  // LDS floats private to a wave
   int n_pack0;          // workgroup kernel: first step that runs on packed tiles (n_ops: none)
+  float ln_inv_n, ln_pad;  // LayerNorm: 1 / d_model and the number of zero-padded features
+  float attn_c;            // log2(e) / sqrt(d_keys)
   unsigned long long* prof;  // profiling build only
 };
 
@@ -145,6 +148,8 @@ struct Lane {
   int g;  // lane >> 4 : k group / C row block
   int ablate;  // timing-experiment mask, 0 in production
   unsigned wo;  // c * 64 + 4 * g : this lane's offset inside a 16-row block of a [.][64] matrix
+  float inv_n, pad_n;  // LayerNorm over the real features: 1 / d_model, 64 - d_model
+  float attn_c;        // softmax scale times log2(e)
 #ifdef CET_PROF
   unsigned long long* prof;  // this wave's stamp trace, or null when the wave is not sampled
   int* pidx;                 // next free entry of the trace
@@ -326,14 +331,15 @@ DEV void layer_norm(f32x4 (&x)[2][4], const NormParams& n, const Lane ln) {
   for (int rt = 0; rt < RT; ++rt) {
     // sums are kept four wide (packed fp32 adds / FMAs) and folded at the end
     const f32x4 s4 = (x[rt][0] + x[rt][1]) + (x[rt][2] + x[rt][3]);
-    const float mean = group_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * (1.0f / DM);
+    const float mean = group_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * ln.inv_n;
     f32x4 q4 = zero4();
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const f32x4 d = x[rt][m] - mean;
       q4 = __builtin_elementwise_fma(d, d, q4);
     }
-    const float var = group_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) * (1.0f / DM);
+    // zero-padded features each contributed mean^2 to the sum of squares
+    const float var = fmaf(-ln.pad_n, mean * mean, group_sum((q4[0] + q4[1]) + (q4[2] + q4[3]))) * ln.inv_n;
     const float inv = __builtin_amdgcn_rsqf(var + 1e-5f);
     const float shift = -mean * inv;
 #pragma unroll
@@ -417,7 +423,7 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
   constexpr int NP = (RQ * RK == 1) ? 4 : (RQ * RK == 2 ? 2 : 1);  // head pairs per group
   // softmax(scale * s) is evaluated as 2^(c s + bias - max) / sum with c = scale * log2(e);
   // bias is 0 for admitted keys and -inf for padded or (causal) future ones.
-  const float c = 0.35355339059327373f * 1.44269504088896340736f;  // float(1/sqrt(8)) * log2 e
+  const float c = ln.attn_c;  // float(1 / sqrt(d_keys)) * log2 e
   const bool upper = (ln.c & 8) != 0;  // lane feeds the second head of a pair
   f32x4 bias[RK][RQ];
 #pragma unroll
@@ -1164,10 +1170,12 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   const int prof_slot = seq / prof_stride;
   const bool prof_on = valid && seq % prof_stride == 0 && prof_slot < PROF_SAMPLES;
   const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)),
+                a.ln_inv_n, a.ln_pad, a.attn_c,
                 prof_on ? a.prof + (size_t)prof_slot * PROF_MAXM : nullptr, &prof_idx};
   PROF_MARK(ln, P_OTHER);
 #else
-  const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4))};
+  const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)),
+                a.ln_inv_n, a.ln_pad, a.attn_c};
 #endif
   Stage st{a.wblk, smem_all, WG ? lds_address(smem_all) : 0u, 0, WG ? a.n_blk : 0, wave, lane};
   if (WG) stage_request(st);  // block 0 travels while the embedding is computed
@@ -1291,7 +1299,8 @@ struct InformerModel {
 };
 
 static bool supported(const cet_informer_cfg& c) {
-  if (c.d_model != DM || c.n_heads != NHEAD || c.d_ff != DM) return false;
+  // narrower models run zero-padded to the kernels' 64 features and 8 heads of 8 (widen())
+  if (c.n_heads != NHEAD || c.d_model < NHEAD || c.d_model > DM || c.d_ff < 1 || c.d_ff > DM) return false;
   if (c.enc_in != 16 && c.enc_in != 32) return false;
   if (c.dec_in != 16 && c.dec_in != 32) return false;
   if (c.c_out < 4 || c.c_out > 64 || c.c_out % 4) return false;
@@ -1346,8 +1355,8 @@ static bool plan(const cet_informer_cfg& c, Dims& d) {
 size_t informer_blob_size(const cet_informer_cfg* c) {
   Dims d;
   if (!supported(*c) || !plan(*c, d)) return 0;
-  const size_t D = DM, F = c->d_ff;
-  const size_t attn = 4 * (D * D + D), ffn = F * D + F + D * F + D;
+  const size_t D = c->d_model, F = c->d_ff, HE = (size_t)(c->d_model / NHEAD) * NHEAD;
+  const size_t attn = 3 * (HE * D + HE) + D * HE + D, ffn = F * D + F + D * F + D;
   size_t n = D * c->enc_in * 3 + D + (size_t)c->seq_len * D;
   n += D * c->dec_in * 3 + D + (size_t)(c->label_len + c->pred_len) * D;
   for (int e = 0; e < d.n_enc; ++e) {
@@ -1368,11 +1377,106 @@ static void conv_taps_major(const float* src, int cout, int cin, std::vector<flo
       for (int c = 0; c < cin; ++c) dst.push_back(src[((size_t)o * cin + c) * 3 + j]);
 }
 
-int informer_create(const cet_informer_cfg* c, const float* wsrc, size_t n, InformerModel** out) {
-  if (!supported(*c)) return CET_ERR_UNSUPPORTED;
+// Zero-pads a model with d_model < 64 (and/or d_ff < 64, d_keys < 8) to the 64-wide layout the
+// kernels are built for, in the caller's tensor order. Model features d and FFN features f keep
+// their index; dimension e of head h moves to 8 h + e. Padded rows / columns, biases, LayerNorm
+// and BatchNorm scales are zero (BatchNorm variance one), so padded features are exactly zero
+// everywhere; LayerNorm and the attention scale take the real sizes from the kernel arguments.
+static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const float* p) {
+  const int D = c.d_model, F = c.d_ff, E = D / NHEAD, HE = E * NHEAD;
+  std::vector<float> v;
+  auto ident = [](int i) { return i; };
+  auto head = [E](int i) { return (i / E) * 8 + i % E; };
+  // matrix [rows][cols][taps] -> [64 or keep][64 or keep][taps]
+  auto mat = [&](int rows, int cols, int taps, bool pad_rows, bool pad_cols, auto rmap, auto cmap) {
+    const int R = pad_rows ? DM : rows, C = pad_cols ? DM : cols;
+    const size_t base = v.size();
+    v.resize(base + (size_t)R * C * taps, 0.f);
+    for (int r = 0; r < rows; ++r)
+      for (int q = 0; q < cols; ++q)
+        for (int t = 0; t < taps; ++t)
+          v[base + ((size_t)rmap(r) * C + cmap(q)) * taps + t] = p[((size_t)r * cols + q) * taps + t];
+    p += (size_t)rows * cols * taps;
+  };
+  auto vec = [&](int n, auto map, float fill = 0.f) {
+    const size_t base = v.size();
+    v.resize(base + DM, fill);
+    for (int i = 0; i < n; ++i) v[base + map(i)] = p[i];
+    p += n;
+  };
+  auto attn = [&]() {
+    for (int k = 0; k < 3; ++k) {
+      mat(HE, D, 1, true, true, head, ident);
+      vec(HE, head);
+    }
+    mat(D, HE, 1, true, true, ident, head);
+    vec(D, ident);
+  };
+  auto ffn = [&]() {
+    mat(F, D, 1, true, true, ident, ident);
+    vec(F, ident);
+    mat(D, F, 1, true, true, ident, ident);
+    vec(D, ident);
+  };
+  const int emb_in[2] = {c.enc_in, c.dec_in};
+  const int emb_len[2] = {c.seq_len, c.label_len + c.pred_len};
+  for (int s = 0; s < 2; ++s) {
+    mat(D, emb_in[s], 3, true, false, ident, ident);
+    vec(D, ident);
+    mat(emb_len[s], D, 1, false, true, ident, ident);  // positional table rows
+  }
+  for (int e = 0; e < d.n_enc; ++e) {
+    const int el = d.enc_layers[e];
+    for (int l = 0; l < el; ++l) {
+      attn();
+      ffn();
+      for (int k = 0; k < 4; ++k) vec(D, ident);  // norm1 g,b, norm2 g,b
+    }
+    if (c.distil)
+      for (int l = 0; l < el - 1; ++l) {
+        mat(D, D, 3, true, true, ident, ident);
+        vec(D, ident);                              // conv bias
+        vec(D, ident);                              // BatchNorm weight
+        vec(D, ident);                              // BatchNorm bias
+        vec(D, ident);                              // running mean
+        vec(D, ident, 1.f);                         // running variance
+      }
+    vec(D, ident);
+    vec(D, ident);
+  }
+  for (int l = 0; l < c.d_layers; ++l) {
+    attn();
+    attn();
+    ffn();
+    for (int k = 0; k < 6; ++k) vec(D, ident);
+  }
+  vec(D, ident);
+  vec(D, ident);
+  mat(c.c_out, D, 1, false, true, ident, ident);
+  v.insert(v.end(), p, p + c.c_out);
+  return v;
+}
+
+int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n_in,
+                    InformerModel** out) {
+  if (!supported(*c_in)) return CET_ERR_UNSUPPORTED;
   Dims d;
-  if (!plan(*c, d)) return CET_ERR_UNSUPPORTED;
-  if (n != informer_blob_size(c)) return CET_ERR_BLOB_SIZE;
+  if (!plan(*c_in, d)) return CET_ERR_UNSUPPORTED;
+  if (n_in != informer_blob_size(c_in)) return CET_ERR_BLOB_SIZE;
+  // from here on everything is 64 wide
+  cet_informer_cfg c64 = *c_in;
+  c64.d_model = DM;
+  c64.d_ff = DM;
+  const cet_informer_cfg* c = &c64;
+  std::vector<float> wide;
+  const float* wsrc = wsrc_in;
+  size_t n = n_in;
+  if (c_in->d_model != DM || c_in->d_ff != DM) {
+    wide = widen(*c_in, d, wsrc_in);
+    wsrc = wide.data();
+    n = wide.size();
+    if (n != informer_blob_size(c)) return CET_ERR_BLOB_SIZE;
+  }
 
   // Re-order the caller's (PyTorch-layout) blob into execution order.
   std::vector<float> v;
@@ -1472,7 +1576,7 @@ int informer_create(const cet_informer_cfg* c, const float* wsrc, size_t n, Info
 
   InformerModel* m = new (std::nothrow) InformerModel;
   if (!m) return CET_ERR_ALLOC;
-  m->cfg = *c;
+  m->cfg = *c_in;
   m->d = d;
   for (int i = 0; i < d.n_attn; ++i) m->attn_per_sample += (size_t)NHEAD * d.attn_len[i] * d.attn_len[i];
   for (int i = 0; i < d.n_taps; ++i) m->taps_per_sample += (size_t)d.tap_rows[i] * DM;
@@ -1563,6 +1667,9 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   if (R < m->d.mem_rows) R = m->d.mem_rows;
   if (R < 12) R = 12;
   a.region_rows = R;
+  a.ln_inv_n = 1.0f / (float)m->cfg.d_model;
+  a.ln_pad = (float)(DM - m->cfg.d_model);
+  a.attn_c = (float)(1.0 / sqrt((double)(m->cfg.d_model / NHEAD))) * 1.44269504088896340736f;
   a.wblk = m->dev_blocks;
   a.n_blk = m->n_blocks;
   static const int ablate = [] {

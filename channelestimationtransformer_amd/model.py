@@ -72,10 +72,13 @@ class _DeviceWeights(nn.Module):
             pass
 
 
-def _attention_holder(d_model):
+def _attention_holder(d_model, n_heads):
+    """AttentionLayer's parameters (attn.py:121-138): d_keys = d_values = d_model // n_heads."""
     n = _Node()
-    for name in ("query_projection", "key_projection", "value_projection", "out_projection"):
-        setattr(n, name, nn.Linear(d_model, d_model))
+    inner = (d_model // n_heads) * n_heads
+    for name in ("query_projection", "key_projection", "value_projection"):
+        setattr(n, name, nn.Linear(d_model, inner))
+    n.out_projection = nn.Linear(inner, d_model)
     return n
 
 
@@ -105,12 +108,12 @@ def _embedding_holder(c_in, d_model, max_len=5000):
     return emb
 
 
-def _encoder_holder(n_layers, d_model, d_ff, distil):
+def _encoder_holder(n_layers, d_model, n_heads, d_ff, distil):
     enc = _Node()
     layers = []
     for _ in range(n_layers):
         lay = _Node()
-        lay.attention = _attention_holder(d_model)
+        lay.attention = _attention_holder(d_model, n_heads)
         _ffn_into(lay, d_model, d_ff, ("norm1", "norm2"))
         layers.append(lay)
     enc.attn_layers = nn.ModuleList(layers)
@@ -151,15 +154,15 @@ class _InformerBase(_DeviceWeights):
         if self._stack:
             self.encoder = _Node()
             self.encoder.encoders = nn.ModuleList(
-                [_encoder_holder(el, d_model, d_ff, distil) for el in depths])
+                [_encoder_holder(el, d_model, n_heads, d_ff, distil) for el in depths])
         else:
-            self.encoder = _encoder_holder(e_layers, d_model, d_ff, distil)
+            self.encoder = _encoder_holder(e_layers, d_model, n_heads, d_ff, distil)
         self.decoder = _Node()
         dec_layers = []
         for _ in range(d_layers):
             lay = _Node()
-            lay.self_attention = _attention_holder(d_model)
-            lay.cross_attention = _attention_holder(d_model)
+            lay.self_attention = _attention_holder(d_model, n_heads)
+            lay.cross_attention = _attention_holder(d_model, n_heads)
             _ffn_into(lay, d_model, d_ff, ("norm1", "norm2", "norm3"))
             dec_layers.append(lay)
         self.decoder.layers = nn.ModuleList(dec_layers)

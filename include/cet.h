@@ -57,6 +57,10 @@ typedef struct cet_informer_cfg {
 } cet_informer_cfg;
 
 /* Number of fp32 values cet_informer_create expects for `cfg` (0 if cfg is unsupported).
+ * Supported: n_heads = 8, 8 <= d_model <= 64, 1 <= d_ff <= 64, enc_in/dec_in in {16, 32},
+ * seq_len <= 30, label_len + pred_len <= 32. The blob always has the model's own dimensions;
+ * models narrower than 64 features are widened with zeros inside cet_informer_create.
+ * Below, d_inner = (d_model / n_heads) * n_heads (models/attn.py:126-133; 48 for d_model 54).
  *
  * Blob order (all tensors in their PyTorch layout, row-major, concatenated):
  *   enc_embedding : tokenConv.weight[d_model,enc_in,3], tokenConv.bias[d_model],
@@ -65,8 +69,9 @@ typedef struct cet_informer_cfg {
  *                   pe[0:label_len+pred_len, d_model]
  *   for each encoder of the stack (stack=1: e_layers, e_layers-1, ... 3 layers; stack=0: one
  *   encoder of e_layers layers):
- *       for each attention layer: query/key/value/out projection weight[d_model,d_model]
- *           + bias[d_model] (4 pairs), conv1.weight[d_ff,d_model], conv1.bias[d_ff],
+ *       for each attention layer: query/key/value projection weight[d_inner,d_model] +
+ *           bias[d_inner], out projection weight[d_model,d_inner] + bias[d_model],
+ *           conv1.weight[d_ff,d_model], conv1.bias[d_ff],
  *           conv2.weight[d_model,d_ff], conv2.bias[d_model], norm1.weight, norm1.bias,
  *           norm2.weight, norm2.bias
  *       then, if distil, for each of the (layers-1) ConvLayers: downConv.weight[d_model,
@@ -99,7 +104,8 @@ int cet_informer_forward(cet_handle h, const float* x_enc, const float* x_dec, f
                          float* attn, int B, void* stream);
 
 /* Debug variant: additionally copies the activations after every stage into `taps`
- * (device, cet_informer_taps_size(h,B) floats; layout [stage][B][rows_of_stage][d_model]). */
+ * (device, cet_informer_taps_size(h,B) floats; layout [stage][B][rows_of_stage][64]; features
+ * d_model..63 of a narrower model are zero). */
 size_t cet_informer_taps_size(cet_handle h, int B);
 int cet_informer_forward_taps(cet_handle h, const float* x_enc, const float* x_dec, float* out,
                               float* attn, float* taps, int B, void* stream);

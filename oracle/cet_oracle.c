@@ -94,33 +94,38 @@ static const float* take(const float** p, size_t n) {
   *p += n;
   return r;
 }
-static void take_attn(const float** p, int D, attn_w* a) {
-  a->wq = take(p, (size_t)D * D); a->bq = take(p, D);
-  a->wk = take(p, (size_t)D * D); a->bk = take(p, D);
-  a->wv = take(p, (size_t)D * D); a->bv = take(p, D);
-  a->wo = take(p, (size_t)D * D); a->bo = take(p, D);
+/* AttentionLayer (attn.py:121-138): d_keys = d_values = d_model // n_heads; the q/k/v
+ * projections are Linear(d_model, d_keys * n_heads), the output projection
+ * Linear(d_values * n_heads, d_model) -- narrower than d_model when it is not a multiple of
+ * n_heads. */
+static void take_attn(const float** p, int D, int H, attn_w* a) {
+  int HE = (D / H) * H;
+  a->wq = take(p, (size_t)HE * D); a->bq = take(p, HE);
+  a->wk = take(p, (size_t)HE * D); a->bk = take(p, HE);
+  a->wv = take(p, (size_t)HE * D); a->bv = take(p, HE);
+  a->wo = take(p, (size_t)D * HE); a->bo = take(p, D);
 }
 
 /* AttentionLayer.forward + FullAttention.forward (attn.py:140-156, 18-36).
  * q_in [L,D], kv_in [S,D] -> out [L,D]; amap (optional) [H,L,S]. */
 static void attention(const float* q_in, int L, const float* kv_in, int S, int D, int H,
                       const attn_w* w, int causal, float* out, float* amap) {
-  int E = D / H;
-  float* q = (float*)malloc(sizeof(float) * L * D);
-  float* k = (float*)malloc(sizeof(float) * S * D);
-  float* v = (float*)malloc(sizeof(float) * S * D);
-  float* ctx = (float*)malloc(sizeof(float) * L * D);
+  int E = D / H, HE = E * H;
+  float* q = (float*)malloc(sizeof(float) * L * HE);
+  float* k = (float*)malloc(sizeof(float) * S * HE);
+  float* v = (float*)malloc(sizeof(float) * S * HE);
+  float* ctx = (float*)malloc(sizeof(float) * L * HE);
   float* sc = (float*)malloc(sizeof(float) * S);
-  linear(q_in, L, D, w->wq, w->bq, D, q);
-  linear(kv_in, S, D, w->wk, w->bk, D, k);
-  linear(kv_in, S, D, w->wv, w->bv, D, v);
+  linear(q_in, L, D, w->wq, w->bq, HE, q);
+  linear(kv_in, S, D, w->wk, w->bk, HE, k);
+  linear(kv_in, S, D, w->wv, w->bv, HE, v);
   float scale = 1.0f / sqrtf((float)E);
   for (int h = 0; h < H; ++h)
     for (int l = 0; l < L; ++l) {
       float mx = -INFINITY;
       for (int s = 0; s < S; ++s) {
         float acc = 0.f;
-        for (int e = 0; e < E; ++e) acc += q[l * D + h * E + e] * k[s * D + h * E + e];
+        for (int e = 0; e < E; ++e) acc += q[l * HE + h * E + e] * k[s * HE + h * E + e];
         /* masked_fill_(triu(1), -inf) happens before the scaling (attn.py:24-30) */
         if (causal && s > l) acc = -INFINITY;
         sc[s] = scale * acc;
@@ -134,11 +139,11 @@ static void attention(const float* q_in, int L, const float* kv_in, int S, int D
       }
       for (int e = 0; e < E; ++e) {
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += sc[s] * v[s * D + h * E + e];
-        ctx[l * D + h * E + e] = acc;
+        for (int s = 0; s < S; ++s) acc += sc[s] * v[s * HE + h * E + e];
+        ctx[l * HE + h * E + e] = acc;
       }
     }
-  linear(ctx, L, D, w->wo, w->bo, D, out);
+  linear(ctx, L, HE, w->wo, w->bo, D, out);
   free(q); free(k); free(v); free(ctx); free(sc);
 }
 
@@ -163,7 +168,7 @@ static void tap(tap_list* tl, const float* x, int rows) {
 static void encoder_layer(float* x, int L, const cet_informer_cfg* c, const float** p,
                           float* amap) {
   int D = c->d_model, F = c->d_ff;
-  attn_w aw; take_attn(p, D, &aw);
+  attn_w aw; take_attn(p, D, c->n_heads, &aw);
   const float* w1 = take(p, (size_t)F * D); const float* b1 = take(p, F);
   const float* w2 = take(p, (size_t)D * F); const float* b2 = take(p, D);
   const float* g1 = take(p, D); const float* be1 = take(p, D);
@@ -221,7 +226,8 @@ static int encoder_fwd(float* x, int L, int n_layers, const cet_informer_cfg* c,
   int distil = c->distil;
   /* weights are stored: all attention layers, then all conv layers, then the norm */
   const float* pa = *p;
-  size_t per_layer = (size_t)4 * ((size_t)D * D + D) + (size_t)c->d_ff * D + c->d_ff +
+  size_t HE = (size_t)(D / H) * H;
+  size_t per_layer = 3 * (HE * D + HE) + ((size_t)D * HE + D) + (size_t)c->d_ff * D + c->d_ff +
                      (size_t)D * c->d_ff + D + 4 * (size_t)D;
   const float* pc = pa + per_layer * n_layers;
   float* y = (float*)malloc(sizeof(float) * (L + 2) * D);
@@ -341,7 +347,7 @@ ORC_API int orc_informer_forward(const cet_informer_cfg* c, const float* blob,
     embedding(x_dec + (size_t)b * Ld * c->dec_in, Ld, c->dec_in, D, &p_dec_emb, xd);
     tap(&tl, xd, Ld);
     for (int l = 0; l < c->d_layers; ++l) {
-      attn_w sa, ca; take_attn(&p, D, &sa); take_attn(&p, D, &ca);
+      attn_w sa, ca; take_attn(&p, D, H, &sa); take_attn(&p, D, H, &ca);
       int F = c->d_ff;
       const float* w1 = take(&p, (size_t)F * D); const float* b1 = take(&p, F);
       const float* w2 = take(&p, (size_t)D * F); const float* b2 = take(&p, D);

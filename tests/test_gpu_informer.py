@@ -116,6 +116,30 @@ def test_other_wirings(name, oracle):
             assert np.abs(a - v[f"{name}/attn_{i}"]).max() < TOL_ATTN
 
 
+@pytest.mark.parametrize("name,dm", [("dm32", 32), ("dm54", 54)])
+def test_shipped_narrow_checkpoints(name, dm, oracle):
+    """The reference ships Transformer checkpoints with d_model 32 and 54 (d_keys 4 and 6; the
+    projections of the 54-wide model are 48 wide because d_keys = d_model // n_heads,
+    models/attn.py:126-133). The library widens them to its 64-feature tiles with zeros; every
+    stage, every attention map and the prediction must still equal the reference's, and the
+    padded feature columns of every stage must be exactly zero."""
+    v = load_npz("informer_dims.npz")
+    args = (16, 16, 16, 25, 10, 3, 5, dm, 8, 4, 3, 64, 0.05, "full", "fixed", "gelu", True, True)
+    m = build("InformerStack", args, sub_dict(v, f"{name}/sd"))
+    pred, taps, attn = run_taps(m, v[f"{name}/x_enc"], v[f"{name}/x_dec"])
+    B = v[f"{name}/x_enc"].shape[0]
+    rows = oracle.tap_rows(m._cfg)
+    for i, t in enumerate(oracle.split_taps(taps, rows, B, 64)):
+        err = np.abs(t[..., :dm] - v[f"{name}/tap_{i}"]).max()
+        assert err < TOL_STAGE, f"{name} stage {i}: {err}"
+        assert not t[..., dm:].any(), f"{name} stage {i}: padded features are not zero"
+    assert np.abs(pred - v[f"{name}/pred"]).max() < TOL_PRED
+    for i, a in enumerate(oracle.split_attn(attn, oracle.attn_lengths(m._cfg), B, 8)):
+        assert np.abs(a - v[f"{name}/attn_{i}"]).max() < TOL_ATTN, f"{name} attention map {i}"
+    out = m.to("cuda")(torch.from_numpy(v[f"{name}/x_enc"]).cuda(), torch.from_numpy(v[f"{name}/x_dec"]).cuda())
+    assert np.array_equal(out[0].cpu().numpy(), pred)
+
+
 def test_module_api_and_attention_nesting(oracle):
     ck = dict(load_npz("informer_ckpt.npz"))
     m = build("InformerStack", DEFAULT_ARGS, ck).cuda()

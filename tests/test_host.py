@@ -42,12 +42,17 @@ def test_blob_sizes_agree_between_library_and_host():
 def test_unsupported_configurations_are_refused():
     L = _cabi.lib()
     cfg = cfg_from_args(DEFAULT_ARGS, True)
-    cfg.d_model = 32
+    cfg.d_model = 128  # wider than the 64-feature tiles
     assert L.cet_informer_blob_size(ctypes.byref(cfg)) == 0
     h = ctypes.c_void_p()
     dummy = np.zeros(4, np.float32)
     rc = L.cet_informer_create(ctypes.byref(cfg), dummy.ctypes.data_as(ctypes.c_void_p), 4, ctypes.byref(h))
     assert rc == 2
+    for narrow in (32, 54):  # narrower models are widened with zeros by the library
+        cfg.d_model = narrow
+        assert L.cet_informer_blob_size(ctypes.byref(cfg)) > 0
+    cfg.d_model, cfg.n_heads = 64, 4
+    assert L.cet_informer_blob_size(ctypes.byref(cfg)) == 0
     rc = L.cet_rnn_create(1, 16, 16, 100, 2, dummy.ctypes.data_as(ctypes.c_void_p), 4, ctypes.byref(h))
     assert rc == 2
     cfg = cfg_from_args(DEFAULT_ARGS, True)

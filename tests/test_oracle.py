@@ -105,3 +105,23 @@ def test_loadbatch_real2complex():
     g = load_npz("loadbatch.npz")
     assert np.array_equal(LoadBatch(g["H"]).numpy(), g["loadbatch"])
     assert np.array_equal(real2complex(g["loadbatch"][:, :5]), g["real2complex"])
+
+
+@pytest.mark.parametrize("name,dm", [("dm32", 32), ("dm54", 54)])
+def test_checker_on_shipped_narrow_checkpoints(name, dm, oracle):
+    """The shipped d_model 32 / 54 InformerStack checkpoints (pred_len 3; with d_model 54 the
+    attention projections are 54 -> 48 -> 54): prediction, every stage and every attention map
+    of the imported reference (tests/golden/make_golden_dims.py)."""
+    from channelestimationtransformer_amd import blobs
+    from conftest import load_npz, sub_dict
+    v = load_npz("informer_dims.npz")
+    cfg = blobs.make_informer_cfg(16, 16, 16, 25, 10, 3, dm, 8, 4, 3, 64, True, True, "gelu")
+    blob = blobs.pack_informer(sub_dict(v, f"{name}/sd"), cfg)
+    assert blob.size == blobs.informer_blob_len(cfg)
+    pred, attn, taps = oracle.informer_forward(cfg, blob, v[f"{name}/x_enc"], v[f"{name}/x_dec"],
+                                               want_attn=True, want_taps=True)
+    assert np.abs(pred - v[f"{name}/pred"]).max() < 5e-6
+    for i, t in enumerate(taps):
+        assert t.shape[-1] == dm and np.abs(t - v[f"{name}/tap_{i}"]).max() < 2e-5, i
+    for i, a in enumerate(attn):
+        assert np.abs(a - v[f"{name}/attn_{i}"]).max() < 5e-6, i
