@@ -11,13 +11,18 @@
 //     layer (all waves need it as B operand) lives in LDS, [sequence][H+4] floats, read as
 //     conflict-free ds_read_b128 (4 k-steps per read).
 //   * Weights are re-packed once at create time into the exact order a wave consumes them:
-//     1 KiB per (k-block of 8, unit tile, gate), so the dominant stream (the whole weight set,
-//     once per time step per workgroup, from L2) is perfectly linear 16 B/lane loads, software
-//     double-buffered one k-block (32 MFMAs) ahead.
+//     1 KiB per (k-block of 8, unit tile, gate), one contiguous stream per wave that covers a
+//     whole time step, so the dominant traffic (the whole weight set, once per time step per
+//     workgroup, from L2) is perfectly linear 16 B/lane loads. A ring of D k-blocks of
+//     registers keeps D loads in flight at all times: a slot is refilled right after its
+//     MFMAs were issued, across unit tiles, layers, barriers and time steps (the stream wraps),
+//     so L2 latency is paid once per launch instead of once per matrix.
+//   * Biases and the encoder Linear live in LDS for the whole rollout.
 //   * The decoder Linear consumes the wave's fresh h straight from the accumulator registers
 //     (k = own units), the four partial sums meet in LDS; the encoder Linear of the next step
 //     consumes that result from registers again. In the closed-loop phase nothing but the
 //     predictions ever goes to HBM.
+#include <cstdio>
 #include <new>
 #include <vector>
 
@@ -35,6 +40,20 @@ constexpr int FP = 32;       // features / encoder width, padded
 constexpr int PSTR = FP + 4; // row stride of the partial-sum / x staging buffers
 
 #define DEV __device__ __forceinline__
+
+// -DCET_PROF: every wave of 16 sampled workgroups accumulates shader-clock ticks per phase of a
+// time step and the host prints the averages after the launch (which it then waits for).
+#ifdef CET_PROF
+constexpr int RP_CATS = 8, RP_SLOTS = 16, RP_WORDS = RP_CATS + 2;
+#define RP_MARK(cat)                                              \
+  {                                                               \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();   \
+    rp_acc[cat] += n_ - rp_t;                                     \
+    rp_t = n_;                                                    \
+  }
+#else
+#define RP_MARK(cat)
+#endif
 
 DEV f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -58,7 +77,7 @@ template <> struct Cell<CET_RNN_GRU> { static constexpr int G = 3, NACC = 4; }; 
 template <> struct Cell<CET_RNN_LSTM> { static constexpr int G = 4, NACC = 4; };  // i, f, g, o
 
 struct RArgs {
-  const float* wstream;  // packed gate weights, [layer][wave][unit tile][x|h][k-block][gate][64][4]
+  const float* wstream;  // packed gate weights, [wave][layer][unit tile][x|h][k-block][gate][64][4]
   const float* bias;     // [layer][2][G*H]   (b_ih, b_hh)
   const float* enc_w;    // [FP][FP] zero padded (row = encoder output unit)
   const float* enc_b;    // [FP]
@@ -67,6 +86,7 @@ struct RArgs {
   const float* x;        // [B][seq][F]
   float* out;            // [B][pred][F]
   int B, seq_len, pred_len, F, IP;  // IP: encoder width padded to 16
+  unsigned long long* prof;         // profiling build only
 };
 
 // C/D row of register r for lane half hh (v_mfma_f32_32x32x2_f32): (r&3) + 8*(r>>2) + 4*hh.
@@ -86,29 +106,84 @@ DEV void kblock(f32x16 (&acc)[Cell<KIND>::NACC], const f32x4 (&wt)[Cell<KIND>::G
   }
 }
 
-template <int N>
-DEV void load_tiles(f32x4 (&dst)[N], const float* src) {
-#pragma unroll
-  for (int t = 0; t < N; ++t) dst[t] = ld4(src + t * 256);
+// k-blocks of weight tiles in flight per wave, by gate count (1 tanh cell, 3 GRU, 4 LSTM): the
+// MFMAs of D-1 k-blocks (64 * 4 * G cycles each) cover the L2 latency of a refill (~2500 cycles).
+#ifndef CET_RNN_D1
+#define CET_RNN_D1 16
+#endif
+#ifndef CET_RNN_D3
+#define CET_RNN_D3 4
+#endif
+#ifndef CET_RNN_D4
+#define CET_RNN_D4 4
+#endif
+constexpr int ring_depth(int kind) {
+  return kind == CET_RNN_TANH ? CET_RNN_D1 : (kind == CET_RNN_GRU ? CET_RNN_D3 : CET_RNN_D4);
 }
 
-// acc += W_part * act^T over nkb k-blocks (nkb a multiple of 2). `ws`: this lane's position in
-// the packed weight stream; `act`: this lane's activation row (+4*hh) in LDS. Weight tiles are
-// kept two k-blocks ahead of the MFMAs that consume them (three register sets in rotation
-// would need runtime indexing; two sets with the reload issued right after the last use of a
-// set give the same distance at half the registers).
-template <int KIND, bool PART_H>
-DEV void run_part(f32x16 (&acc)[Cell<KIND>::NACC], const float* ws, const float* act, int nkb) {
-  constexpr int G = Cell<KIND>::G;
-  f32x4 w0[G], w1[G];
-  load_tiles<G>(w0, ws);
-  load_tiles<G>(w1, ws + G * 256);
-  for (int kb = 0; kb < nkb; kb += 2) {
-    const f32x4 b0 = ld4(act + 8 * kb), b1 = ld4(act + 8 * kb + 8);
-    kblock<KIND, PART_H>(acc, w0, b0);
-    if (kb + 2 < nkb) load_tiles<G>(w0, ws + (size_t)(kb + 2) * G * 256);
-    kblock<KIND, PART_H>(acc, w1, b1);
-    if (kb + 3 < nkb) load_tiles<G>(w1, ws + (size_t)(kb + 3) * G * 256);
+// The wave's weight stream as a ring of D register sets, fetched with buffer loads: the
+// descriptor covers the wave's stream of one time step, the lane offset is a constant VGPR, the
+// position in the stream a scalar byte offset (`off`, the next k-block to fetch) that wraps at
+// the end of the stream, and the G tiles of a k-block sit in the instruction's immediate offset.
+template <int G, int D>
+struct WRing {
+  f32x4 w[D][G];
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned lane_off;    // 16 * lane
+  unsigned off, total;  // bytes
+};
+
+template <int G, int D>
+DEV void ring_refill(WRing<G, D>& r, const int d) {
+#pragma unroll
+  for (int t = 0; t < G; ++t)
+    r.w[d][t] = __builtin_bit_cast(
+        f32x4, __builtin_amdgcn_raw_buffer_load_b128(r.rsrc, r.lane_off + t * 1024, r.off, 0));
+  r.off += G * 1024;
+  if (r.off == r.total) r.off = 0;
+}
+
+// Keeps the compiler's scheduler from moving anything across this point: the refill of a ring
+// slot must stay behind the MFMAs that read the slot, or it needs a second register set.
+DEV void pin_order() { __builtin_amdgcn_sched_barrier(0); }
+
+// acc += W_seg * act^T over one segment of the stream of nblk k-blocks (a multiple of D). On
+// entry ring slot d holds the segment's block d. `act`: this lane's activation row (+4*hh) in
+// LDS, read D k-blocks ahead as well.
+template <int KIND, bool PART_H, int D>
+DEV void segment(f32x16 (&acc)[Cell<KIND>::NACC], WRing<Cell<KIND>::G, D>& r, const float* act,
+                 const int nblk) {
+  f32x4 b[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) b[d] = ld4(act + 8 * d);
+  for (int kb = 0; kb < nblk; kb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      kblock<KIND, PART_H>(acc, r.w[d], b[d]);
+      ring_refill(r, d);
+      if (kb + D + d < nblk) b[d] = ld4(act + 8 * (kb + D + d));
+      pin_order();
+    }
+  }
+}
+
+// The layer-0 input segment: D k-blocks in the stream (so that every segment is a multiple of
+// the ring depth) of which the first nvalid <= 4 carry weights; the rest is fetched and dropped.
+// The activation row holds FP = 32 values, so reading 4 k-blocks of it is always in bounds.
+template <int KIND, int D>
+DEV void segment_input(f32x16 (&acc)[Cell<KIND>::NACC], WRing<Cell<KIND>::G, D>& r,
+                       const float* act, const int nvalid) {
+  constexpr int NB = D < 4 ? D : 4;
+  f32x4 b[NB];
+#pragma unroll
+  for (int d = 0; d < NB; ++d) b[d] = ld4(act + 8 * d);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (d < NB) {
+      if (d < nvalid) kblock<KIND, false>(acc, r.w[d], b[d < NB ? d : 0]);
+    }
+    ring_refill(r, d);
+    pin_order();
   }
 }
 
@@ -124,6 +199,11 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
   float* xbuf = smem;                       // [BT][PSTR]  encoder output (layer-0 input)
   float* part = xbuf + BT * PSTR;           // [4][BT][PSTR] decoder partial sums
   float* hbuf = part + 4 * BT * PSTR;       // [NL][BT][HS]
+  float* lbias = hbuf + NL * BT * HS;       // [NL][2][G*H]  (b_ih, b_hh)
+  float* lencw = lbias + NL * 2 * G * H;    // [FP][PSTR]    encoder weight rows
+  float* lencb = lencw + FP * PSTR;         // [FP]
+  constexpr int D = ring_depth(KIND);
+  static_assert((H / 8) % D == 0, "segment lengths must be multiples of the ring depth");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -133,8 +213,23 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
   const int b0 = blockIdx.x * BT;
   const int bj = (b0 + j < a.B) ? b0 + j : a.B - 1;  // tail tile: replay the last sequence
 
+  // weight ring: blocks per wave and time step = UT * (D + H/8) for layer 0 (input segment
+  // padded to D) + UT * 2 * H/8 for every further layer
+  WRing<G, D> ring;
+  ring.total = (unsigned)(UT * (D + H / 8) + (NL - 1) * UT * 2 * (H / 8)) * G * TILE * 4;
+  ring.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wstream) + (size_t)wave * (ring.total / 4), 0, ring.total, 0x00020000);
+  ring.lane_off = lane * 16;
+  ring.off = 0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring_refill(ring, d);
+
   for (int i = tid; i < (BT * PSTR * 5 + NL * BT * HS) / 4; i += 256)
     st4(smem + 4 * i, f32x4{0, 0, 0, 0});
+  for (int i = tid; i < NL * 2 * G * H / 4; i += 256) st4(lbias + 4 * i, ld4(a.bias + 4 * i));
+  for (int i = tid; i < FP * FP / 4; i += 256)
+    st4(lencw + (i / (FP / 4)) * PSTR + 4 * (i % (FP / 4)), ld4(a.enc_w + 4 * i));
+  if (tid < FP / 4) st4(lencb + 4 * tid, ld4(a.enc_b + 4 * tid));
 
   f32x16 cst[LSTM ? NL : 1][LSTM ? UT : 1];  // LSTM cell state of this wave's units
 #pragma unroll
@@ -155,16 +250,19 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
   };
   load_x(0, xin);
   __syncthreads();
+#ifdef CET_PROF
+  unsigned long long rp_acc[RP_CATS] = {};
+  const unsigned long long rp_t0 = __builtin_amdgcn_s_memtime(), rp_w0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long rp_t = rp_t0;
+#endif
 
   const int n_steps = a.seq_len + a.pred_len - 1;
   for (int idx = 0; idx < n_steps; ++idx) {
     // The weights do not change between steps, which invites the compiler to hoist hundreds of
     // loop-invariant loads (all biases, decoder rows) out of the time loop and pin them in
     // registers. Making the base pointers opaque per iteration keeps them where they are used.
-    const float *wstream = a.wstream, *bias_all = a.bias, *enc_w = a.enc_w, *enc_b = a.enc_b,
-                *dec_w = a.dec_w, *dec_b = a.dec_b;
-    asm volatile("" : "+s"(wstream), "+s"(bias_all), "+s"(enc_w), "+s"(enc_b), "+s"(dec_w),
-                 "+s"(dec_b));
+    const float *dec_w = a.dec_w, *dec_b = a.dec_b;
+    asm volatile("" : "+s"(dec_w), "+s"(dec_b));
     // ---- encoder Linear: xe^T = We * x^T + be, from registers; wave 0 publishes it ----
     f32x4 xnext[4];
 #pragma unroll
@@ -174,13 +272,13 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
       f32x16 e;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = ld4(enc_b + 8 * q + 4 * hh);
+        const f32x4 bv = ld4(lencb + 8 * q + 4 * hh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) e[4 * q + i] = bv[i];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 wv = ld4(enc_w + j * FP + 8 * q + 4 * hh);
+        const f32x4 wv = ld4(lencw + j * PSTR + 8 * q + 4 * hh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) e = mfma32(wv[i], xin[q][i], e);
       }
@@ -190,6 +288,7 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
             f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]});
     }
     __syncthreads();
+    RP_MARK(0)
 
     const bool decode = idx >= a.seq_len - 1;  // decoder output needed from here on
     f32x16 dec_acc;
@@ -197,17 +296,12 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
     for (int r = 0; r < 16; ++r) dec_acc[r] = 0.f;
 
     // ---- the layers ---------------------------------------------------------------------
-    const float* wp = wstream;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const float* in_buf = l == 0 ? xbuf : hbuf + (l - 1) * BT * HS;
       const int in_stride = l == 0 ? PSTR : HS;
-      const int nkb_x = l == 0 ? a.IP / 8 : H / 8;
       float* hl = hbuf + l * BT * HS;
-      const size_t tile_floats = (size_t)(nkb_x + H / 8) * G * TILE;  // one (wave, unit tile)
-      const float* ws = wp + (size_t)wave * UT * tile_floats + lane * 4;
-      wp += (size_t)4 * UT * tile_floats;
-      const float* bi = bias_all + (size_t)l * 2 * G * H;
+      const float* bi = lbias + l * 2 * G * H;
       const float* bh = bi + G * H;
 
       f32x16 hnew[UT];
@@ -232,10 +326,14 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
             }
           }
         }
-        run_part<KIND, false>(acc, ws, in_buf + j * in_stride + 4 * hh, nkb_x);
-        ws += (size_t)nkb_x * G * TILE;
-        run_part<KIND, true>(acc, ws, hl + j * HS + 4 * hh, H / 8);
-        ws += (size_t)(H / 8) * G * TILE;
+        RP_MARK(1)
+        if (l == 0)  // encoder width / 8 valid k-blocks (2 or 4) in a segment of D
+          segment_input<KIND, D>(acc, ring, in_buf + j * in_stride + 4 * hh, a.IP / 8);
+        else
+          segment<KIND, false, D>(acc, ring, in_buf + j * in_stride + 4 * hh, H / 8);
+        RP_MARK(2)
+        segment<KIND, true, D>(acc, ring, hl + j * HS + 4 * hh, H / 8);
+        RP_MARK(3)
 
         // cell update, lane-local
         f32x16 hprev;
@@ -262,7 +360,10 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
             const float fg = sigmoidf_(acc[1][r]);
             const float gg = tanhf_(acc[2][r]);
             const float og = sigmoidf_(acc[3][r]);
-            const float cv = fg * cst[LSTM ? l : 0][LSTM ? u : 0][r] + ig * gg;
+            // two rounded products and a rounded sum, as the elementwise tensor ops of
+            // nn.LSTM compute it (no contraction into an fma, whose choice of operand would
+            // otherwise be left to the optimiser)
+            const float cv = __fadd_rn(__fmul_rn(fg, cst[LSTM ? l : 0][LSTM ? u : 0][r]), __fmul_rn(ig, gg));
             cst[LSTM ? l : 0][LSTM ? u : 0][r] = cv;
             hv = og * tanhf_(cv);
           }
@@ -278,7 +379,9 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
           }
         }
       }
+      RP_MARK(4)
       __syncthreads();  // every wave has finished reading the old h of this layer
+      RP_MARK(5)
 #pragma unroll
       for (int u = 0; u < UT; ++u)
 #pragma unroll
@@ -292,6 +395,7 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
               f32x4{dec_acc[4 * q], dec_acc[4 * q + 1], dec_acc[4 * q + 2], dec_acc[4 * q + 3]});
       }
       __syncthreads();
+      RP_MARK(6)
     }
 
     // ---- decoder output = bias + the four waves' partial sums (fixed order) ----------------
@@ -313,7 +417,17 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) xin[q] = xnext[q];
+    RP_MARK(7)
   }
+#ifdef CET_PROF
+  const int rp_stride = gridDim.x >= RP_SLOTS ? gridDim.x / RP_SLOTS : 1;
+  if (blockIdx.x % rp_stride == 0 && blockIdx.x / rp_stride < RP_SLOTS && lane == 0) {
+    unsigned long long* dst = a.prof + ((size_t)(blockIdx.x / rp_stride) * 4 + wave) * RP_WORDS;
+    for (int i = 0; i < RP_CATS; ++i) dst[i] = rp_acc[i];
+    dst[RP_CATS] = __builtin_amdgcn_s_memtime() - rp_t0;
+    dst[RP_CATS + 1] = __builtin_amdgcn_s_memrealtime() - rp_w0;
+  }
+#endif
 }
 
 }  // namespace
@@ -359,6 +473,10 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   const float* p = w;
   const float* enc_w = p; p += (size_t)I * F;
   const float* enc_b = p; p += I;
+  const int D = ring_depth(kind);
+  if (IP / 8 > D || IP / 8 > 4 || (H / 8) % D) return CET_ERR_UNSUPPORTED;
+  struct LayerW { const float *w_ih, *w_hh; int in, in_p; };
+  std::vector<LayerW> lw;
   std::vector<float> stream, bias;
   for (int l = 0; l < layers; ++l) {
     const int in = l == 0 ? I : H;          // true input width
@@ -369,12 +487,18 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     const float* b_hh = p; p += (size_t)G * H;
     bias.insert(bias.end(), b_ih, b_ih + (size_t)G * H);
     bias.insert(bias.end(), b_hh, b_hh + (size_t)G * H);
-    for (int wave = 0; wave < 4; ++wave)
+    lw.push_back({w_ih, w_hh, in, in_p});
+  }
+  // one stream per wave in consumption order: [layer][unit tile][input segment | hidden segment]
+  // [k-block][gate][64 lanes][4]; the layer-0 input segment is padded to D k-blocks
+  for (int wave = 0; wave < 4; ++wave)
+    for (int l = 0; l < layers; ++l)
       for (int u = 0; u < UT; ++u)
         for (int part = 0; part < 2; ++part) {
-          const float* W = part == 0 ? w_ih : w_hh;
-          const int K = part == 0 ? in : H, KP = part == 0 ? in_p : H;
-          for (int kb = 0; kb < KP / 8; ++kb)
+          const float* W = part == 0 ? lw[l].w_ih : lw[l].w_hh;
+          const int K = part == 0 ? lw[l].in : H;
+          const int nblk = part == 0 ? (l == 0 ? D : H / 8) : H / 8;
+          for (int kb = 0; kb < nblk; ++kb)
             for (int g = 0; g < G; ++g)
               for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 4; ++i) {
@@ -383,7 +507,6 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
                   stream.push_back(k < K ? W[((size_t)g * H + unit) * K + k] : 0.f);
                 }
         }
-  }
   const float* dec_w = p; p += (size_t)F * H;
   const float* dec_b = p; p += F;
   if ((size_t)(p - w) != n) return CET_ERR_BLOB_SIZE;
@@ -433,7 +556,8 @@ void rnn_destroy(RnnModel* m) {
 template <int KIND, int UT, int NL>
 static int launch(const RArgs& a, hipStream_t stream) {
   constexpr int H = 128 * UT;
-  const size_t lds = sizeof(float) * (size_t)(BT * PSTR * 5 + NL * BT * (H + 4));
+  const size_t lds = sizeof(float) * (size_t)(BT * PSTR * 5 + NL * BT * (H + 4) +
+                                              NL * 2 * Cell<KIND>::G * H + FP * PSTR + FP);
   CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_rollout_kernel<KIND, UT, NL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((a.B + BT - 1) / BT);
@@ -460,11 +584,45 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   a.wstream = m->wstream; a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b;
   a.dec_w = m->dec_w; a.dec_b = m->dec_b; a.x = x; a.out = out;
   a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F; a.IP = m->IP;
+#ifdef CET_PROF
+  static unsigned long long* prof_dev = nullptr;
+  const size_t prof_bytes = (size_t)RP_SLOTS * 4 * RP_WORDS * sizeof(unsigned long long);
+  if (!prof_dev) CET_HIP(hipMalloc(&prof_dev, prof_bytes));
+  CET_HIP(hipMemsetAsync(prof_dev, 0, prof_bytes, stream));
+  a.prof = prof_dev;
+#endif
+  int rc;
   switch (m->kind) {
-    case CET_RNN_TANH: return launch_kind<CET_RNN_TANH>(m, a, stream);
-    case CET_RNN_GRU: return launch_kind<CET_RNN_GRU>(m, a, stream);
-    default: return launch_kind<CET_RNN_LSTM>(m, a, stream);
+    case CET_RNN_TANH: rc = launch_kind<CET_RNN_TANH>(m, a, stream); break;
+    case CET_RNN_GRU: rc = launch_kind<CET_RNN_GRU>(m, a, stream); break;
+    default: rc = launch_kind<CET_RNN_LSTM>(m, a, stream); break;
   }
+#ifdef CET_PROF
+  if (rc == CET_OK) {
+    static const char* names[RP_CATS] = {"encoder+barrier", "bias init", "x part", "h part",
+                                         "cell update", "barrier (h read)", "h store+barrier",
+                                         "decode tail"};
+    unsigned long long h[RP_SLOTS * 4 * RP_WORDS];
+    CET_HIP(hipStreamSynchronize(stream));
+    CET_HIP(hipMemcpy(h, prof_dev, sizeof h, hipMemcpyDeviceToHost));
+    double cat[RP_CATS + 2] = {};
+    int n = 0;
+    for (int s = 0; s < RP_SLOTS * 4; ++s) {
+      if (!h[s * RP_WORDS + RP_CATS]) continue;
+      ++n;
+      for (int i = 0; i < RP_CATS + 2; ++i) cat[i] += (double)h[s * RP_WORDS + i];
+    }
+    if (n) {
+      const int steps = seq_len + pred_len - 1;
+      fprintf(stderr, "[cet rnn prof] kind %d B %d steps %d: %.0f ticks/step, shader clock %.3f GHz\n",
+              m->kind, B, steps, cat[RP_CATS] / n / steps, cat[RP_CATS] / cat[RP_CATS + 1] * 0.1);
+      for (int i = 0; i < RP_CATS; ++i)
+        fprintf(stderr, "[cet rnn prof]   %-18s %9.0f ticks/step  %5.1f %%\n", names[i],
+                cat[i] / n / steps, 100.0 * cat[i] / cat[RP_CATS]);
+    }
+  }
+#endif
+  return rc;
 }
 
 }  // namespace cet
