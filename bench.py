@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--pred-len", type=int, default=25, help="rollout horizon of the recurrent workloads")
     ap.add_argument("--no-attention-maps", action="store_true",
                     help="informer: do not materialise the attention maps (output_attention=False)")
+    ap.add_argument("--h-share", type=int, default=1,
+                    help="lmmse: block fading, one channel matrix per this many consecutive REs")
+    ap.add_argument("--geometry", default="reference", choices=["reference", "scaled"],
+                    help="e2e: 4x2 antennas per subcarrier sample, or 16x4 (eight 4x2 predictor "
+                         "sequences per subcarrier)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-secondary", action="store_true")
     return ap.parse_args()
@@ -170,13 +175,20 @@ def cpu_baseline_lmmse(Nr, Ns, no, budget_s=12.0):
             "sample": f"{n} REs {Nr}x{Ns}, float64 C restatement (oracle/cet_oracle.c), {threads} threads"}
 
 
-def lmmse_inputs(N, Nr, Ns, no, dev, seed):
+def lmmse_inputs(N, Nr, Ns, no, dev, seed, h_share=1):
+    """y [N,Nr], H [ceil(N/h_share),Nr,Ns] (one matrix per h_share consecutive REs), x [N,Ns]."""
     g = torch.Generator(device=dev).manual_seed(seed)
-    H = torch.randn(N, Nr, Ns, 2, device=dev, generator=g) * 0.5 ** 0.5
+    nb = -(-N // h_share)
+    H = torch.randn(nb, Nr, Ns, 2, device=dev, generator=g) * 0.5 ** 0.5
     bits = torch.randint(0, 2, (N, Ns, 2), device=dev, generator=g).float() * 2 - 1
     xs = torch.view_as_complex((bits * 0.5 ** 0.5).contiguous())
     Hc = torch.view_as_complex(H)
-    y = torch.einsum("nrs,ns->nr", Hc, xs)
+    if h_share == 1:
+        y = torch.einsum("nrs,ns->nr", Hc, xs)
+    else:
+        pad = nb * h_share - N
+        xp = torch.cat([xs, xs.new_zeros(pad, Ns)]) if pad else xs
+        y = torch.einsum("brs,bks->bkr", Hc, xp.reshape(nb, h_share, Ns)).reshape(nb * h_share, Nr)[:N]
     y = y + torch.view_as_complex(torch.randn(N, Nr, 2, device=dev, generator=g) * (no / 2) ** 0.5)
     return y.contiguous(), Hc, xs
 
@@ -272,6 +284,15 @@ def main():
                                    "hbm_GBps": 688.0 * N / d3 / 1e9,
                                    "hbm_frac": 688.0 * N / d3 / 1e9 / PEAK_HBM_GBS}
             del y, H
+            yb, Hb, _xs = lmmse_inputs(N, 16, 4, 0.1, dev, 0, 14)
+            def step3c():
+                cet.lmmse(yb, Hb, 0.1, h_share=14)
+            _w, db = timed_loop(step3c, 10, 2, False, dev)
+            bpr = 688.0 - 512.0 * 13 / 14
+            extra["lmmse_16x4_block_fading_14"] = {
+                "REs_per_s": N / db, "kernel_ms": db * 1e3, "N": N, "bytes_per_RE": bpr,
+                "hbm_GBps": bpr * N / db / 1e9, "hbm_frac": bpr * N / db / 1e9 / PEAK_HBM_GBS}
+            del yb, Hb
             # the reference-sized equalizer shapes (4 x 2 of EndtoEndtest.py, 8 x 4)
             for (nr, ns) in ((8, 4), (4, 2)):
                 Nv = 1 << 24
@@ -300,40 +321,58 @@ def main():
         # Transformer prediction of 5 future slots per subcarrier sample -> LMMSE over the 14
         # OFDM symbols of each predicted slot (4 receive antennas, 2 streams) -> hard-decision
         # QPSK bit errors and per-slot NMSE; ranks hold disjoint subcarrier ranges.
-        S = args.batch or 3276 * 8
+        scaled = args.geometry == "scaled"
+        S = args.batch or 3276 * 8   # predictor sequences per GPU
         n_sym, no = 14, 0.05
+        Nr, Nt = (16, 4) if scaled else (4, 2)
         model, ck = make_informer(False)
         # the checkpoint predicts CDL-B channels: the reference's 192 stored sequences, tiled
         cr = np.load(os.path.join(GOLDEN, "cr_pairs.npz"))
         real = np.concatenate([cr["data_30"], cr["data_36"], cr["data_60"]])
         real = np.roll(real, 7 * rank, axis=0)[np.arange(S) % real.shape[0]]
-        h_hist = torch.from_numpy(real[:, :25]).to(dev)
-        h_future = torch.from_numpy(real[:, 25:30]).to(dev)
+        real = torch.from_numpy(real).to(dev)
+        if scaled:  # eight stored 4x2 sequences make one 16x4 subcarrier sample
+            real = e2e.ungroup_antennas(real[:S - S % 8], Nr, Nt)
+        h_hist, h_future = real[:, :25].contiguous(), real[:, 25:30].contiguous()
+        n_sc = h_hist.shape[0]
         out["data"] = "the reference's stored CDL-B sequences (CR_data_30/36/60), tiled; synthetic QPSK + AWGN"
         g = torch.Generator(device=dev).manual_seed(rank)
         y, xs = e2e.transmit(h_future, n_sym, no, g)
         holder = {}
 
         def step():
-            h_hat = e2e.predict_slots(model, h_hist, 10, 5)
+            if scaled:
+                h_hat = e2e.predict_slots_grouped(model, h_hist, 10, 5)
+            else:
+                h_hat = e2e.predict_slots(model, h_hist, 10, 5)
             x_hat, _ = e2e.equalize_slots(h_hat, y, no)
             holder["sums"] = {"nmse": metrics.nmse_partial_sums(h_hat, h_future),
                               "bits": metrics.qpsk_bit_errors(x_hat, xs),
                               "bits_perfect": metrics.qpsk_bit_errors(x_hat, xs)}
 
         wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
+        # outside the timed region: the same link equalized with the true channel, and with the
+        # prediction error's variance passed to the equalizer
+        x_true, _ = e2e.equalize_slots(h_future.to(torch.complex64), y, no)
+        holder["sums"]["bits_perfect"] = metrics.qpsk_bit_errors(x_true, xs)
+        h_hat = (e2e.predict_slots_grouped if scaled else e2e.predict_slots)(model, h_hist, 10, 5)
+        err_var = float((h_hat - h_future).abs().pow(2).mean())
+        x_ev, _ = e2e.equalize_slots(h_hat, y, no, err_var)
+        bits_ev = metrics.qpsk_bit_errors(x_ev, xs)
+        metrics.all_reduce_sums(bits_ev)
         res = e2e.reduce(holder["sums"])  # the path's only collective (RCCL)
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         if dist_on:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t)
-        n_re = S * 5 * n_sym
+        n_re = n_sc * 5 * n_sym
         out.update({
             "metric": "channel predictions/s (Transformer prediction + LMMSE equalization + BER/NMSE)",
             "value": S * n_gpus * args.steps / wall, "unit": "predictions/s",
             "ms_per_step": wall / args.steps * 1e3, "dtype": "f32",
-            "config": {"workload": f"end to end: InformerStack default configuration on {S} subcarrier "
-                                   f"samples per GPU (4x2 channel), LMMSE 4x2 on {n_re} REs "
+            "config": {"workload": f"end to end: InformerStack default configuration on {S} 4x2 antenna "
+                                   f"groups = {n_sc} subcarrier samples per GPU ({Nr}x{Nt} channel), "
+                                   f"block-fading LMMSE {Nr}x{Nt} on {n_re} REs "
                                    f"(5 slots x {n_sym} symbols), QPSK, no={no}",
                        "parallelism": f"dp{n_gpus} (subcarrier ranges)"},
             "roofline": {"bound": "mfma", "achieved": INFORMER_FLOP * S / dev_s / 1e12,
@@ -342,17 +381,20 @@ def main():
                          "kernel": "whole step (informer_kernel + lmmse + torch glue)",
                          "kernel_ms": dev_s * 1e3},
             "equalized_REs_per_s": n_re * n_gpus * args.steps / wall,
-            "ber": res["ber"], "nmse_db_per_slot": [round(v, 3) for v in res["nmse_db"]],
+            "ber": res["ber"], "ber_perfect_csi": res["ber_perfect_csi"],
+            "ber_with_err_var": float(bits_ev[0] / bits_ev[1]), "err_var": err_var,
+            "nmse_db_per_slot": [round(v, 3) for v in res["nmse_db"]],
         })
 
     elif args.workload == "lmmse":
         Nr, Ns, no = 16, 4, 0.1
         N = args.batch or 3276 * 14 * 1024  # 46,964,736 REs = 32.3 GB of operands
-        y, H, xs = lmmse_inputs(N, Nr, Ns, no, dev, rank)
+        hs = max(1, args.h_share)
+        y, H, xs = lmmse_inputs(N, Nr, Ns, no, dev, rank, hs)
         holder = {}
 
         def step():
-            holder["x"], holder["ne"] = cet.lmmse(y, H, no)
+            holder["x"], holder["ne"] = cet.lmmse(y, H, no, h_share=hs)
 
         wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
         bits = metrics.qpsk_bit_errors(holder["x"], xs)
@@ -361,16 +403,19 @@ def main():
         if dist_on:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t)
-        gbs = LMMSE_BYTES[(Nr, Ns)] * N / dev_s / 1e9
+        bytes_re = LMMSE_BYTES[(Nr, Ns)] - Nr * Ns * 8 * (1.0 - 1.0 / hs)  # H once per block
+        gbs = bytes_re * N / dev_s / 1e9
         out.update({
             "metric": "LMMSE-equalized REs/s", "value": N * n_gpus * args.steps / wall, "unit": "REs/s",
             "ms_per_step": wall / args.steps * 1e3, "dtype": "complex64 (f32 arithmetic)",
-            "config": {"workload": f"LMMSE {Nr}x{Ns}, {N} REs per GPU (3276 sc x 14 sym x 1024 slots), no=0.1",
+            "config": {"workload": f"LMMSE {Nr}x{Ns}, {N} REs per GPU (3276 sc x 14 sym x 1024 slots), no=0.1"
+                                   + (f", block fading: one H per {hs} REs, {bytes_re:.1f} B/RE" if hs > 1 else ""),
                        "parallelism": f"dp{n_gpus}"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": gbs / PEAK_HBM_GBS, "traffic": measured_traffic("lmmse", N),
+                         "frac": gbs / PEAK_HBM_GBS,
+                         "traffic": measured_traffic("lmmse", N) if hs == 1 else None,
                          "kernel": "lmmse_tiled<16,4,2>",
-                         "kernel_ms": dev_s * 1e3, "bytes_per_launch": LMMSE_BYTES[(Nr, Ns)] * N},
+                         "kernel_ms": dev_s * 1e3, "bytes_per_launch": bytes_re * N},
             "ber": float(bits[0] / bits[1]),
         })
         if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:

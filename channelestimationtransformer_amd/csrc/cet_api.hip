@@ -145,42 +145,52 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
                      static_cast<hipStream_t>(stream));
 }
 
+// `x_hat` receives LLRs when `llr` is set (no_eff is then not written and may be null).
 static int lmmse_checked(const float* y, const float* H, int no_mode, float no_scalar,
-                         const float* no_dev, float* x_hat, float* no_eff, long N, int Nr, int Ns,
-                         int variant, void* stream) {
-  if (N < 0 || Nr <= 0 || Ns <= 0) return CET_ERR_INVALID_ARG;
+                         const float* no_dev, float* x_hat, float* no_eff, bool llr, long N,
+                         int h_share, int Nr, int Ns, int variant, void* stream) {
+  if (N < 0 || Nr <= 0 || Ns <= 0 || h_share < 1 || h_share > 65536) return CET_ERR_INVALID_ARG;
   if (no_mode < CET_NO_SCALAR || no_mode > CET_NO_PER_RE_RX) return CET_ERR_INVALID_ARG;
   if (N == 0) return CET_OK;
-  if (!y || !H || !x_hat || !no_eff) return CET_ERR_INVALID_ARG;
+  if (!y || !H || !x_hat || (!llr && !no_eff)) return CET_ERR_INVALID_ARG;
   if (no_mode != CET_NO_SCALAR && !no_dev) return CET_ERR_INVALID_ARG;
   if (no_mode == CET_NO_SCALAR && !(no_scalar > 0.f)) return CET_ERR_INVALID_ARG;
   if (Ns > Nr) return CET_ERR_UNSUPPORTED;
-  return lmmse_launch(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, variant,
-                      static_cast<hipStream_t>(stream));
+  return lmmse_launch(y, H, no_mode, no_scalar, no_dev, x_hat, llr ? nullptr : no_eff, N, Nr, Ns,
+                      h_share, variant, static_cast<hipStream_t>(stream));
 }
 
 int cet_lmmse(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
               float* x_hat, float* no_eff, long N, int Nr, int Ns, void* stream) {
-  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, 0, stream);
+  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, false, N, 1, Nr, Ns, 0,
+                       stream);
 }
 
 int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scalar,
                      const float* no_dev, float* x_hat, float* no_eff, long N, int Nr, int Ns,
                      void* stream) {
-  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, Nr, Ns, 1, stream);
+  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, false, N, 1, Nr, Ns, 1,
+                       stream);
 }
 
 int cet_lmmse_llr(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
                   float* llr, long N, int Nr, int Ns, void* stream) {
-  if (N < 0 || Nr <= 0 || Ns <= 0) return CET_ERR_INVALID_ARG;
-  if (no_mode < CET_NO_SCALAR || no_mode > CET_NO_PER_RE_RX) return CET_ERR_INVALID_ARG;
-  if (N == 0) return CET_OK;
-  if (!y || !H || !llr) return CET_ERR_INVALID_ARG;
-  if (no_mode != CET_NO_SCALAR && !no_dev) return CET_ERR_INVALID_ARG;
-  if (no_mode == CET_NO_SCALAR && !(no_scalar > 0.f)) return CET_ERR_INVALID_ARG;
-  if (Ns > Nr) return CET_ERR_UNSUPPORTED;
-  return lmmse_launch(y, H, no_mode, no_scalar, no_dev, llr, nullptr, N, Nr, Ns, 0,
-                      static_cast<hipStream_t>(stream));
+  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, llr, nullptr, true, N, 1, Nr, Ns, 0,
+                       stream);
+}
+
+int cet_lmmse_block(const float* y, const float* H, int no_mode, float no_scalar,
+                    const float* no_dev, float* x_hat, float* no_eff, long N, int h_share, int Nr,
+                    int Ns, void* stream) {
+  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, false, N, h_share, Nr, Ns,
+                       0, stream);
+}
+
+int cet_lmmse_block_llr(const float* y, const float* H, int no_mode, float no_scalar,
+                        const float* no_dev, float* llr, long N, int h_share, int Nr, int Ns,
+                        void* stream) {
+  return lmmse_checked(y, H, no_mode, no_scalar, no_dev, llr, nullptr, true, N, h_share, Nr, Ns, 0,
+                       stream);
 }
 
 int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float* pabs2inv,

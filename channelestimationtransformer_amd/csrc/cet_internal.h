@@ -25,7 +25,7 @@ struct RnnModel;
 
 // launchers implemented next to their kernels
 int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
-                 float* x_hat, float* no_eff, long N, int Nr, int Ns, int variant,
+                 float* x_hat, float* no_eff, long N, int Nr, int Ns, int hshare, int variant,
                  hipStream_t stream);
 
 int ls_nn_launch(const float* y, const int* src, const float* pinv, const float* pabs2inv, float no,

@@ -19,6 +19,11 @@
 //   * one RE is handled by LPR lanes that split the receive antennas; the partial Gram
 //     matrices are combined with cross-lane adds and every lane then carries out the small
 //     Hermitian solve (Cholesky, triangular inverse) in registers.
+// Block fading (`hshare` > 1): H holds one matrix per `hshare` consecutive REs (the symbols of
+// a slot over which a predicted channel is held). The DMA gathers every RE's H from its block,
+// so HBM sees each matrix once (the re-reads of the following REs hit L1/L2) and the
+// arithmetic per RE is exactly that of the per-RE layout: results are bit-identical to running
+// on the expanded H.
 // With S = no*I the kernel uses A' = H^H H + no*I, for which d = 1 - no*(A'^-1)_ss and
 // no_eff = t/(1-t), t = no*(A'^-1)_ss: no cancellation in no_eff at high SNR.
 #include <cstdlib>
@@ -170,12 +175,13 @@ __global__ __launch_bounds__(256) void lmmse_direct(const float* __restrict__ y,
                                                     const float* __restrict__ H, float no_scalar,
                                                     const float* __restrict__ no_dev,
                                                     float* __restrict__ x_hat,
-                                                    float* __restrict__ no_eff, long N) {
+                                                    float* __restrict__ no_eff, long N,
+                                                    int hshare) {
   const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   Gram<NS> g;
   g.clear();
-  const float2* h2 = reinterpret_cast<const float2*>(H) + n * (NR * NS);
+  const float2* h2 = reinterpret_cast<const float2*>(H) + (hshare > 1 ? n / hshare : n) * (NR * NS);
   const float2* y2 = reinterpret_cast<const float2*>(y) + n * NR;
   for (int r = 0; r < NR; ++r) {
     float hr[NS], hi[NS];
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
                                                   const float* __restrict__ no_dev,
                                                   float* __restrict__ x_hat,
                                                   float* __restrict__ no_eff, long N,
-                                                  long n_tiles) {
+                                                  long n_tiles, int hshare) {
   constexpr int T = 64 / LPR;             // REs per tile
   constexpr int HB = NR * NS * 8;         // bytes of H per RE
   constexpr int YB = NR * 8;              // bytes of y per RE
@@ -298,7 +304,29 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
     const char* hb = reinterpret_cast<const char*>(H) + re0 * HB;
     const char* yb = reinterpret_cast<const char*>(y) + re0 * YB;
     const long last = N - 1 - re0;  // >= T-1 for a full tile
-    if (last >= T - 1) {
+    if (hshare > 1) {
+      // block fading: RE re0 + tt takes H of block (re0 + tt) / hshare. The block and position
+      // of re0 are wave-uniform; tt + rem < T + hshare is small, so the float quotient is exact.
+      const long blk0 = re0 / hshare;
+      const int rem = (int)(re0 - blk0 * hshare);
+      const float inv = 1.0f / (float)hshare;
+      const char* hb0 = reinterpret_cast<const char*>(H) + blk0 * HB;
+#pragma unroll
+      for (int i = 0; i < H_INSTR; ++i) {
+        int tt = (i * 64 + lane) / CH;
+        const unsigned chunk = hoff[i] - (unsigned)tt * HB;
+        if (tt > last) tt = (int)last;
+        const int q = (int)(((float)(tt + rem) + 0.5f) * inv);
+        dma16(hb0 + (size_t)q * HB + chunk, hdst + i * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < Y_INSTR; ++i) {
+        unsigned off = yoff[i];
+        const long tt = (i * 64 + lane) / CY;
+        if (tt > last) off -= (unsigned)(tt - last) * YB;
+        dma16(yb + off, ydst + i * 1024);
+      }
+    } else if (last >= T - 1) {
 #pragma unroll
       for (int i = 0; i < H_INSTR; ++i) dma16(hb + hoff[i], hdst + i * 1024);
 #pragma unroll
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
 
 template <int NR, int NS, int LPR>
 int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
-                 float* x_hat, float* no_eff, long N, hipStream_t stream) {
+                 float* x_hat, float* no_eff, long N, int hshare, hipStream_t stream) {
   constexpr int T = 64 / LPR;
   const long n_tiles = (N + T - 1) / T;
   int dev = 0, cus = 256;
@@ -481,10 +509,10 @@ int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, c
   if (grid > n_tiles) grid = n_tiles;
   if (no_mode == CET_NO_SCALAR) {
     hipLaunchKernelGGL((lmmse_tiled<NR, NS, LPR, false>), dim3((unsigned)grid), dim3(64), 0, stream,
-                       y, H, no_scalar, no_dev, x_hat, no_eff, N, n_tiles);
+                       y, H, no_scalar, no_dev, x_hat, no_eff, N, n_tiles, hshare);
   } else {
     hipLaunchKernelGGL((lmmse_tiled<NR, NS, LPR, true>), dim3((unsigned)grid), dim3(64), 0, stream,
-                       y, H, no_scalar, no_dev, x_hat, no_eff, N, n_tiles);
+                       y, H, no_scalar, no_dev, x_hat, no_eff, N, n_tiles, hshare);
   }
   CET_HIP(hipGetLastError());
   return CET_OK;
@@ -492,20 +520,20 @@ int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, c
 
 template <int NR, int NS>
 int launch_direct(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
-                  float* x_hat, float* no_eff, long N, hipStream_t stream) {
+                  float* x_hat, float* no_eff, long N, int hshare, hipStream_t stream) {
   const dim3 block(256), grid((unsigned)((N + 255) / 256));
   switch (no_mode) {
     case CET_NO_SCALAR:
       hipLaunchKernelGGL((lmmse_direct<NR, NS, CET_NO_SCALAR>), grid, block, 0, stream, y, H,
-                         no_scalar, no_dev, x_hat, no_eff, N);
+                         no_scalar, no_dev, x_hat, no_eff, N, hshare);
       break;
     case CET_NO_PER_RE:
       hipLaunchKernelGGL((lmmse_direct<NR, NS, CET_NO_PER_RE>), grid, block, 0, stream, y, H,
-                         no_scalar, no_dev, x_hat, no_eff, N);
+                         no_scalar, no_dev, x_hat, no_eff, N, hshare);
       break;
     default:
       hipLaunchKernelGGL((lmmse_direct<NR, NS, CET_NO_PER_RE_RX>), grid, block, 0, stream, y, H,
-                         no_scalar, no_dev, x_hat, no_eff, N);
+                         no_scalar, no_dev, x_hat, no_eff, N, hshare);
   }
   CET_HIP(hipGetLastError());
   return CET_OK;
@@ -519,27 +547,27 @@ constexpr int lanes_per_re() {
 
 template <int NR, int NS>
 int dispatch(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
-             float* x_hat, float* no_eff, long N, int variant, hipStream_t stream) {
+             float* x_hat, float* no_eff, long N, int hshare, int variant, hipStream_t stream) {
   if (variant == 1 || no_mode == CET_NO_PER_RE_RX)
-    return launch_direct<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, stream);
+    return launch_direct<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);
   constexpr int LPR = lanes_per_re<NR, NS>();
   static const int lpr_override = [] {
     const char* e = getenv("CET_LMMSE_LPR");  // timing experiments only
     return e ? atoi(e) : 0;
   }();
   if (LPR == 2 && lpr_override == 1)
-    return launch_tiled<NR, NS, 1>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, stream);
-  return launch_tiled<NR, NS, LPR>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, stream);
+    return launch_tiled<NR, NS, 1>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);
+  return launch_tiled<NR, NS, LPR>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);
 }
 
 }  // namespace
 
 int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
-                 float* x_hat, float* no_eff, long N, int Nr, int Ns, int variant,
+                 float* x_hat, float* no_eff, long N, int Nr, int Ns, int hshare, int variant,
                  hipStream_t stream) {
 #define CET_CASE(NR, NS) \
   if (Nr == NR && Ns == NS) \
-    return dispatch<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, variant, stream);
+    return dispatch<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, variant, stream);
   CET_CASE(16, 4) CET_CASE(16, 2) CET_CASE(16, 1)
   CET_CASE(8, 4) CET_CASE(8, 2) CET_CASE(8, 1)
   CET_CASE(4, 4) CET_CASE(4, 2) CET_CASE(4, 1)

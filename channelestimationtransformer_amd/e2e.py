@@ -34,6 +34,34 @@ def predict_slots(model, h_hist, label_len, pred_len):
     return real2complex(out).reshape(S, pred_len, Nr, Nt)
 
 
+def group_antennas(h, nr0=4, nt0=2):
+    """Splits a channel [S, T, Nr, Nt] into the (Nr/nr0)*(Nt/nt0) sub-arrays of nr0 x nt0 antenna
+    pairs a predictor trained on nr0 x nt0 channels takes: returns [S*G, T, nr0, nt0], the groups
+    of a subcarrier sample adjacent (group g = (receive block, transmit block) row-major)."""
+    S, T, Nr, Nt = h.shape
+    if Nr % nr0 or Nt % nt0:
+        raise RuntimeError(f"{Nr}x{Nt} does not split into {nr0}x{nt0} groups")
+    h = h.reshape(S, T, Nr // nr0, nr0, Nt // nt0, nt0).permute(0, 2, 4, 1, 3, 5)
+    return h.reshape(S * (Nr // nr0) * (Nt // nt0), T, nr0, nt0)
+
+
+def ungroup_antennas(hg, Nr, Nt):
+    """Inverse of `group_antennas`: [S*G, T, nr0, nt0] -> [S, T, Nr, Nt]."""
+    SG, T, nr0, nt0 = hg.shape
+    gr, gt = Nr // nr0, Nt // nt0
+    h = hg.reshape(SG // (gr * gt), gr, gt, T, nr0, nt0).permute(0, 3, 1, 4, 2, 5)
+    return h.reshape(SG // (gr * gt), T, Nr, Nt)
+
+
+def predict_slots_grouped(model, h_hist, label_len, pred_len, nr0=4, nt0=2):
+    """`predict_slots` for an array larger than the one the predictor was trained on (the
+    16 x 4 geometry with the reference's 4 x 2 checkpoints): every nr0 x nt0 group of antenna
+    pairs is one sequence of the batch. h_hist [S, seq_len, Nr, Nt] -> [S, pred_len, Nr, Nt]."""
+    _, _, Nr, Nt = h_hist.shape
+    return ungroup_antennas(predict_slots(model, group_antennas(h_hist, nr0, nt0), label_len, pred_len),
+                            Nr, Nt)
+
+
 def predict_slots_recurrent(model, h_hist, pred_len):
     """Same for the GRU / LSTM / RNN predictors (`test_data`, HPC/python/Evaluate.py:147-157)."""
     S, _, Nr, Nt = h_hist.shape
@@ -68,18 +96,20 @@ def equalize_slots(h_hat, y, no, err_var=0.0):
     """h_hat complex [S, P, Nr, Nt] (one estimate per slot), y complex [S, P, n_sym, Nr].
     Returns (x_hat [S, P, n_sym, Nt], no_eff [S, P, n_sym, Nt]). `err_var` (scalar or
     broadcastable to [S, P, Nr, Nt]): variance of the estimation error of every h_hat entry;
-    it enters the noise covariance as no + sum over streams of err_var per receive antenna."""
+    it enters the noise covariance as no + sum over streams of err_var per receive antenna. The
+    slot's estimate is not expanded over the symbols: the equalizer's block-fading entry point
+    reads one matrix per slot."""
     S, P, n_sym, Nr = y.shape
     Nt = h_hat.shape[3]
     N = S * P * n_sym
-    H = h_hat.unsqueeze(2).expand(S, P, n_sym, Nr, Nt).reshape(N, Nr, Nt)
-    if isinstance(err_var, torch.Tensor) or float(err_var) != 0.0:
+    H = h_hat.reshape(S * P, Nr, Nt)  # one matrix per slot, shared by its n_sym elements
+    if not isinstance(err_var, torch.Tensor) or err_var.dim() == 0:
+        noise = float(no) + Nt * float(err_var)  # the same variance on every receive antenna
+    else:
         ev = torch.as_tensor(err_var, dtype=torch.float32, device=y.device)
         ev = torch.broadcast_to(ev, h_hat.shape).sum(-1)  # [S, P, Nr]
         noise = (ev + float(no)).unsqueeze(2).expand(S, P, n_sym, Nr).reshape(N, Nr).contiguous()
-    else:
-        noise = float(no)
-    x_hat, no_eff = lmmse(y.reshape(N, Nr), H, noise)
+    x_hat, no_eff = lmmse(y.reshape(N, Nr), H, noise, h_share=n_sym)
     return x_hat.reshape(S, P, n_sym, Nt), no_eff.reshape(S, P, n_sym, Nt)
 
 
@@ -97,8 +127,8 @@ def equalize_slots_llr(h_hat, y, no):
     S, P, n_sym, Nr = y.shape
     Nt = h_hat.shape[3]
     N = S * P * n_sym
-    H = h_hat.unsqueeze(2).expand(S, P, n_sym, Nr, Nt).reshape(N, Nr, Nt)
-    return lmmse_llr(y.reshape(N, Nr), H, float(no)).reshape(S, P, n_sym, Nt, 2)
+    H = h_hat.reshape(S * P, Nr, Nt)
+    return lmmse_llr(y.reshape(N, Nr), H, float(no), h_share=n_sym).reshape(S, P, n_sym, Nt, 2)
 
 
 def run(model, h_hist, h_future, label_len, pred_len, n_sym=14, no=0.1, seed=0, err_var=0.0,

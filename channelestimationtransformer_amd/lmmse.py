@@ -12,19 +12,22 @@ import torch
 from . import ops  # noqa: F401
 
 
-def _prepare(y, H, no):
+def _prepare(y, H, no, h_share=1):
     """Validates the flat operands; returns (y, H, no tensor, scalar no, noise mode)."""
     if not (torch.is_complex(y) and torch.is_complex(H)):
         raise RuntimeError("y and H must be complex tensors")
     y = y.to(torch.complex64).contiguous()
     H = H.to(torch.complex64).contiguous()
-    if H.dim() != 3 or y.dim() != 2 or y.shape != H.shape[:2]:
-        raise RuntimeError(f"expected y [N,Nr] and H [N,Nr,Ns], got {tuple(y.shape)}, {tuple(H.shape)}")
+    h_share = int(h_share)
+    if (H.dim() != 3 or y.dim() != 2 or h_share < 1 or y.shape[1] != H.shape[1]
+            or H.shape[0] != -(-y.shape[0] // h_share)):
+        raise RuntimeError(f"expected y [N,Nr] and H [ceil(N/h_share),Nr,Ns], got {tuple(y.shape)}, "
+                           f"{tuple(H.shape)}, h_share={h_share}")
     if isinstance(no, torch.Tensor) and no.dim() > 0:
         no_t = no.to(device=y.device, dtype=torch.float32).contiguous()
-        if tuple(no_t.shape) == (H.shape[0],):
+        if tuple(no_t.shape) == (y.shape[0],):
             mode = 1
-        elif tuple(no_t.shape) == tuple(H.shape[:2]):
+        elif tuple(no_t.shape) == tuple(y.shape):
             mode = 2
         else:
             raise RuntimeError(f"`no` must be a scalar, [N] or [N,Nr]; got {tuple(no_t.shape)}")
@@ -35,23 +38,27 @@ def _prepare(y, H, no):
     return y, H, no_t, no_s, mode
 
 
-def lmmse(y, H, no, direct=False):
+def lmmse(y, H, no, direct=False, h_share=1):
     """y [N, Nr] complex64, H [N, Nr, Ns] complex64 (CUDA); `no`: python float, tensor [N]
     (per resource element) or tensor [N, Nr] (diagonal noise+interference covariance).
-    Returns (x_hat [N, Ns] complex64, no_eff [N, Ns] float32)."""
-    y, H, no_t, no_s, mode = _prepare(y, H, no)
+    Returns (x_hat [N, Ns] complex64, no_eff [N, Ns] float32).
+    `h_share` > 1 (block fading): H is [ceil(N / h_share), Nr, Ns] and resource element n uses
+    H[n // h_share], one estimate held over h_share consecutive elements; the results equal
+    those of the expanded H bit for bit while HBM reads every matrix once."""
+    y, H, no_t, no_s, mode = _prepare(y, H, no, h_share)
     x, ne = torch.ops.cet.lmmse(torch.view_as_real(y), torch.view_as_real(H), no_t, no_s, mode,
-                                bool(direct))
+                                bool(direct), int(h_share))
     return torch.view_as_complex(x), ne
 
 
-def lmmse_llr(y, H, no):
+def lmmse_llr(y, H, no, h_share=1):
     """Equalizer and QPSK demapper in one kernel: same operands as `lmmse`, returns the bit
     log-likelihood ratios [N, Ns, 2] float32, ln(P(b=1)/P(b=0)) with bit 0 on the positive axis
     (what a `Demapper("app", "qam", 2)` makes of `lmmse`'s outputs, HPC/python/EvaluateE2E.py:
     292-319)."""
-    y, H, no_t, no_s, mode = _prepare(y, H, no)
-    return torch.ops.cet.lmmse_llr(torch.view_as_real(y), torch.view_as_real(H), no_t, no_s, mode)
+    y, H, no_t, no_s, mode = _prepare(y, H, no, h_share)
+    return torch.ops.cet.lmmse_llr(torch.view_as_real(y), torch.view_as_real(H), no_t, no_s, mode,
+                                   int(h_share))
 
 
 class StreamManagement:

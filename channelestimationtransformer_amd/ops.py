@@ -72,27 +72,41 @@ def _(x, handle, pred_len):
 
 @torch.library.custom_op("cet::lmmse", mutates_args=())
 def lmmse(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: float,
-          no_mode: int, direct: bool) -> tuple[torch.Tensor, torch.Tensor]:
-    """y [N,Nr,2], H [N,Nr,Ns,2] float32 (interleaved complex) -> x_hat [N,Ns,2], no_eff [N,Ns]."""
+          no_mode: int, direct: bool, h_share: int = 1) -> tuple[torch.Tensor, torch.Tensor]:
+    """y [N,Nr,2], H [ceil(N/h_share),Nr,Ns,2] float32 (interleaved complex) -> x_hat [N,Ns,2],
+    no_eff [N,Ns]. h_share > 1: block fading, RE n uses H[n // h_share]."""
     dev = _dev_check(y, H)
     y = y.contiguous()
     H = H.contiguous()
-    N, Nr, Ns = H.shape[0], H.shape[1], H.shape[2]
+    N, Nr, Ns = y.shape[0], H.shape[1], H.shape[2]
+    _block_check(N, H.shape[0], h_share, direct)
     x_hat = torch.empty((N, Ns, 2), dtype=torch.float32, device=dev)
     no_eff = torch.empty((N, Ns), dtype=torch.float32, device=dev)
     no_dev = no.contiguous() if no_mode != 0 else None
     L = _cabi.lib()
-    fn = L.cet_lmmse_direct if direct else L.cet_lmmse
     with torch.cuda.device(dev):
-        rc = fn(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar), _ptr(no_dev), _ptr(x_hat),
-                _ptr(no_eff), ctypes.c_long(N), Nr, Ns, _cabi.current_stream_ptr(dev))
+        if h_share > 1:
+            rc = L.cet_lmmse_block(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar), _ptr(no_dev),
+                                   _ptr(x_hat), _ptr(no_eff), ctypes.c_long(N), h_share, Nr, Ns,
+                                   _cabi.current_stream_ptr(dev))
+        else:
+            fn = L.cet_lmmse_direct if direct else L.cet_lmmse
+            rc = fn(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar), _ptr(no_dev), _ptr(x_hat),
+                    _ptr(no_eff), ctypes.c_long(N), Nr, Ns, _cabi.current_stream_ptr(dev))
     _cabi.check(rc, "cet_lmmse")
     return x_hat, no_eff
 
 
+def _block_check(N, n_h, h_share, direct=False):
+    if h_share < 1 or n_h != -(-N // h_share):
+        raise RuntimeError(f"H holds {n_h} matrices; {N} REs with h_share={h_share} need {-(-N // max(h_share, 1))}")
+    if direct and h_share > 1:
+        raise RuntimeError("the direct kernel has no block-fading entry point")
+
+
 @lmmse.register_fake
-def _(y, H, no, no_scalar, no_mode, direct):
-    N, Ns = H.shape[0], H.shape[2]
+def _(y, H, no, no_scalar, no_mode, direct, h_share=1):
+    N, Ns = y.shape[0], H.shape[2]
     return y.new_empty((N, Ns, 2)), y.new_empty((N, Ns))
 
 
@@ -138,25 +152,33 @@ def _(x_hat, x_true):
 
 @torch.library.custom_op("cet::lmmse_llr", mutates_args=())
 def lmmse_llr(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: float,
-              no_mode: int) -> torch.Tensor:
-    """y [N,Nr,2], H [N,Nr,Ns,2] float32 -> QPSK bit LLRs [N,Ns,2] (equalizer + demapper fused)."""
+              no_mode: int, h_share: int = 1) -> torch.Tensor:
+    """y [N,Nr,2], H [ceil(N/h_share),Nr,Ns,2] float32 -> QPSK bit LLRs [N,Ns,2] (equalizer +
+    demapper fused)."""
     dev = _dev_check(y, H)
     y = y.contiguous()
     H = H.contiguous()
-    N, Nr, Ns = H.shape[0], H.shape[1], H.shape[2]
+    N, Nr, Ns = y.shape[0], H.shape[1], H.shape[2]
+    _block_check(N, H.shape[0], h_share)
     llr = torch.empty((N, Ns, 2), dtype=torch.float32, device=dev)
     no_dev = no.contiguous() if no_mode != 0 else None
+    L = _cabi.lib()
     with torch.cuda.device(dev):
-        rc = _cabi.lib().cet_lmmse_llr(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar),
-                                       _ptr(no_dev), _ptr(llr), ctypes.c_long(N), Nr, Ns,
+        if h_share > 1:
+            rc = L.cet_lmmse_block_llr(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar),
+                                       _ptr(no_dev), _ptr(llr), ctypes.c_long(N), h_share, Nr, Ns,
                                        _cabi.current_stream_ptr(dev))
+        else:
+            rc = L.cet_lmmse_llr(_ptr(y), _ptr(H), no_mode, ctypes.c_float(no_scalar),
+                                 _ptr(no_dev), _ptr(llr), ctypes.c_long(N), Nr, Ns,
+                                 _cabi.current_stream_ptr(dev))
     _cabi.check(rc, "cet_lmmse_llr")
     return llr
 
 
 @lmmse_llr.register_fake
-def _(y, H, no, no_scalar, no_mode):
-    return y.new_empty((H.shape[0], H.shape[2], 2))
+def _(y, H, no, no_scalar, no_mode, h_share=1):
+    return y.new_empty((y.shape[0], H.shape[2], 2))
 
 
 @torch.library.custom_op("cet::ls_nn", mutates_args=())

@@ -170,6 +170,20 @@ int cet_lmmse_direct(const float* y, const float* H, int no_mode, float no_scala
 int cet_lmmse_llr(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
                   float* llr, long N, int Nr, int Ns, void* stream);
 
+/* Block fading: cet_lmmse / cet_lmmse_llr for a channel estimate that is held over `h_share`
+ * consecutive REs, as when one predicted channel serves the OFDM symbols of a slot (the
+ * prediction of LocalSimulations/Predict.py:99-120 feeding the equalizer call of
+ * EndtoEndtest.py:191). H is [ceil(N / h_share), Nr, Ns]: RE n uses H[n / h_share]; y, the noise
+ * arguments and the outputs stay per RE, and the results are bit-identical to cet_lmmse on the
+ * expanded H. HBM reads H once per block (512 / h_share instead of 512 B per RE at 16x4).
+ * 1 <= h_share <= 65536. */
+int cet_lmmse_block(const float* y, const float* H, int no_mode, float no_scalar,
+                    const float* no_dev, float* x_hat, float* no_eff, long N, int h_share, int Nr,
+                    int Ns, void* stream);
+int cet_lmmse_block_llr(const float* y, const float* H, int no_mode, float no_scalar,
+                        const float* no_dev, float* llr, long N, int h_share, int Nr, int Ns,
+                        void* stream);
+
 /* ---- LS channel estimate with nearest-neighbour interpolation ------------------------------ */
 
 /* Per-stream least-squares estimate at the pilots, spread over the resource grid by nearest

@@ -127,3 +127,36 @@ def test_device_channel_generator():
     assert abs(10 * np.log10(snr) - 20.0) < 0.2                          # 20 dB by default
     again, _ = synth.channel_histories_device(2048, "cuda:0", seed=3)
     assert torch.equal(noisy, again)                                     # seeded
+
+
+def test_scaled_geometry_groups_antenna_pairs(model):
+    """16 x 4 channel with the 4 x 2 checkpoint: every 4 x 2 group of antenna pairs is one
+    predictor sequence. The grouped prediction must place exactly the per-group predictions,
+    and the 16 x 4 block-fading equalization with it must work end to end."""
+    h_hist, h_future = _cdl_b_channels()          # 192 sequences of a 4x2 channel
+    big_hist = e2e.ungroup_antennas(h_hist, 16, 4)   # 24 subcarrier samples of a 16x4 channel
+    big_future = e2e.ungroup_antennas(h_future, 16, 4)
+    assert big_hist.shape == (24, 25, 16, 4)
+    assert torch.equal(e2e.group_antennas(big_hist), h_hist)
+    # entry (rx, tx) of sample s comes from group (rx // 4, tx // 2) = sequence 8 s + 2 (rx // 4) + tx // 2
+    assert torch.equal(big_hist[3, :, 9, 3], h_hist[8 * 3 + 2 * 2 + 1, :, 1, 1])
+    small = e2e.predict_slots(model, h_hist, 10, 5)
+    big = e2e.predict_slots_grouped(model, big_hist, 10, 5)
+    assert torch.equal(e2e.group_antennas(big), small)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y, x = e2e.transmit(big_future.to(torch.complex64), 14, 0.05, g)
+    x_hat, no_eff = e2e.equalize_slots(big, y, 0.05)
+    assert x_hat.shape == (24, 5, 14, 4) and no_eff.shape == (24, 5, 14, 4)
+    # the eight stored sequences that make up a sample are strongly correlated, so the 16 x 4
+    # matrix is poorly conditioned and the -14 dB prediction error costs bit errors; telling the
+    # equalizer about that error (err_var) must help, and the true channel must do best
+    ber = lambda xh: float((lambda b: b[0] / b[1])(cet.metrics.qpsk_bit_errors(xh, x)))
+    err_var = float((big - big_future).abs().pow(2).mean())
+    x_ev, _ = e2e.equalize_slots(big, y, 0.05, err_var)
+    x_true, _ = e2e.equalize_slots(big_future.to(torch.complex64), y, 0.05)
+    assert ber(x_true) <= ber(x_ev) <= ber(x_hat) < 0.3
+    # equalizing with the slot's matrix expanded over the symbols gives the same numbers
+    H = big.unsqueeze(2).expand(24, 5, 14, 16, 4).reshape(-1, 16, 4)
+    x_ref, ne_ref = cet.lmmse(y.reshape(-1, 16), H, 0.05)
+    assert torch.equal(torch.view_as_real(x_ref.reshape(x_hat.shape)), torch.view_as_real(x_hat))
+    assert torch.equal(ne_ref.reshape(no_eff.shape), no_eff)

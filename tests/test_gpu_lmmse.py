@@ -169,3 +169,31 @@ def test_ls_estimator_nearest_neighbour(oracle):
     x_hat, no_eff = cet.LMMSEEqualizer(rg, cet.StreamManagement(np.array([[1]]), 2))(
         [torch.from_numpy(y).cuda(), h_hat, err_var, 0.3])
     assert x_hat.shape == (b, 1, 2, 12 * 64) and torch.isfinite(no_eff).all()
+
+
+@pytest.mark.parametrize("Nr,Ns", [(16, 4), (8, 4), (4, 2), (2, 1)])
+@pytest.mark.parametrize("N,h_share", [(14 * 300, 14), (14 * 300 - 5, 14), (4099, 3), (1000, 1000),
+                                       (77, 2000), (64, 1)])
+def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, oracle):
+    """One channel matrix held over h_share consecutive resource elements (a predicted slot):
+    the block-fading entry points must return, bit for bit, what the per-element entry points
+    return on the expanded H — ragged last block, ragged last tile, every noise mode, the fused
+    demapper — and the float64 checker's values within the usual tolerance."""
+    nb = -(-N // h_share)
+    y, _, _ = synth.lmmse_problem(N, Nr, Ns, 0.1, seed=N + Nr + h_share)
+    _, Hb, _ = synth.lmmse_problem(nb, Nr, Ns, 0.1, seed=7 * N + Ns)
+    H = np.repeat(Hb, h_share, axis=0)[:N]
+    yt, Hbt, Ht = (torch.from_numpy(a).cuda() for a in (y, Hb, H))
+    rng = np.random.default_rng(N)
+    per_re = torch.from_numpy(rng.uniform(0.02, 1.0, N).astype(np.float32)).cuda()
+    per_rx = torch.from_numpy(rng.uniform(0.02, 1.0, (N, Nr)).astype(np.float32)).cuda()
+    for no in (0.1, per_re, per_rx):
+        x0, ne0 = cet.lmmse(yt, Ht, no)
+        x1, ne1 = cet.lmmse(yt, Hbt, no, h_share=h_share)
+        assert torch.equal(torch.view_as_real(x0), torch.view_as_real(x1)) and torch.equal(ne0, ne1)
+    want_x, want_ne = oracle.lmmse(y, H, 0.1)
+    x1, ne1 = cet.lmmse(yt, Hbt, 0.1, h_share=h_share)
+    assert close(x1.cpu().numpy(), want_x) and close(ne1.cpu().numpy(), want_ne)
+    assert torch.equal(cet.lmmse_llr(yt, Ht, 0.1), cet.lmmse_llr(yt, Hbt, 0.1, h_share=h_share))
+    with pytest.raises(RuntimeError):
+        cet.lmmse(yt, Hbt[:-1] if nb > 1 else Ht[:0], 0.1, h_share=h_share)

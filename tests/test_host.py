@@ -114,3 +114,15 @@ def test_synthetic_generators_are_seeded():
     assert a.shape == (4, 30, 4, 2) and np.array_equal(a, b)
     y, H, x = synth.lmmse_problem(10, 16, 4, 0.1, 0)
     assert y.shape == (10, 16) and H.shape == (10, 16, 4) and x.shape == (10, 4)
+
+
+def test_antenna_grouping_round_trip():
+    from channelestimationtransformer_amd import e2e
+    g = torch.Generator().manual_seed(0)
+    h = torch.randn(6, 7, 16, 4, generator=g)
+    grouped = e2e.group_antennas(h)
+    assert grouped.shape == (6 * 8, 7, 4, 2)
+    assert torch.equal(e2e.ungroup_antennas(grouped, 16, 4), h)
+    assert torch.equal(grouped[8 * 2 + 2 * 3 + 1, :, 2, 1], h[2, :, 4 * 3 + 2, 2 * 1 + 1])
+    with pytest.raises(RuntimeError):
+        e2e.group_antennas(torch.zeros(1, 2, 6, 4))
