@@ -199,7 +199,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun, also at N = 1
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:

@@ -14,5 +14,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_informer_$c -- python3 $REPO/bench.py --steps 3 --warmup 1 --skip-cpu-baseline --skip-secondary > $OUT/pmc_informer_$c.log 2>&1 || exit 1
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_informer_nomaps_$c -- python3 $REPO/bench.py --steps 3 --warmup 1 --skip-cpu-baseline --skip-secondary --no-attention-maps > $OUT/pmc_informer_nomaps_$c.log 2>&1 || exit 1
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_lmmse_$c -- python3 $REPO/bench.py --workload lmmse --batch 8388608 --steps 3 --warmup 1 --skip-cpu-baseline > $OUT/pmc_lmmse_$c.log 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_lstm_$c -- python3 $REPO/bench.py --workload lstm --pred-len 5 --steps 3 --warmup 1 --skip-cpu-baseline > $OUT/pmc_lstm_$c.log 2>&1 || exit 1
 done
 cd $REPO && python3 tools/summarize_profile.py $OUT $TAG

@@ -24,6 +24,10 @@ PASSES = {
     "informer_nomaps": ("informer_kernel", "bench.py --no-attention-maps (B=4096)", 4096, INFORMER_IO),
     "lmmse": ("lmmse", "bench.py --workload lmmse --batch 8388608 (16x4)", 8388608,
               (16 + 16 * 4 + 4) * 8 + 4 * 4),
+    # recurrent rollout: input + predictions per sequence (the 3.25 MB weight set is read once
+    # from HBM and then streamed from L2 every time step, which these counters do not see)
+    "lstm": ("rnn_rollout_kernel", "bench.py --workload lstm --pred-len 5 (B=8192)", 8192,
+             25 * 16 * 4 + 5 * 16 * 4),
 }
 
 
