@@ -224,7 +224,11 @@ DEV void stage_request(Stage& st) {
 // successor. The barrier also tells that every wave is done with the block before, whose
 // buffer the new request overwrites.
 DEV const float* stage_acquire(Stage& st) {
+#ifdef CET_EXP_NOBARRIER  // timing experiment: what the workgroup barrier costs (results invalid)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
   const float* cur = st.buf + ((st.next - 1) & 1) * WBLK;
   stage_request(st);
   return cur;
