@@ -275,6 +275,17 @@ def main():
             extra[f"informer_output_attention_{not want_maps}"] = {
                 "predictions_per_s": B / d2, "kernel_ms": d2 * 1e3,
                 "mfma_frac": INFORMER_FLOP * B / d2 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+            # the same step fed from and returning to pinned host memory (Predict.py:99-117
+            # moves every batch numpy -> GPU -> numpy); never the headline value
+            xh, xdh = x.cpu().pin_memory(), xd.cpu().pin_memory()
+            oh = torch.empty(B, 5, 16).pin_memory()
+            def step_host():
+                r = model(xh.to(dev, non_blocking=True), xdh.to(dev, non_blocking=True))
+                oh.copy_(r[0] if want_maps else r, non_blocking=True)
+            _w, dh = timed_loop(step_host, max(5, args.steps // 5), 2, False, dev)
+            extra["informer_with_host_transfers"] = {
+                "predictions_per_s": B / dh, "step_ms": dh * 1e3,
+                "note": "pinned host input (x_enc, x_dec) -> device -> forward -> prediction to pinned host"}
             N = 1 << 23
             y, H, _xs = lmmse_inputs(N, 16, 4, 0.1, dev, 0)
             def step3():
@@ -311,7 +322,7 @@ def main():
                 xr = cet.LoadBatch(nb[:, :25]).to(dev)
                 def step4():
                     rm.test_data(xr, 5, dev)
-                w4, d4 = timed_loop(step4, 5, 1, False, dev)
+                w4, d4 = timed_loop(step4, 10, 2, False, dev)
                 fl = RNN_FLOP_PER_STEP[kind] * 29 * 8192
                 extra[f"{kind}_rollout_B8192_pred5"] = {
                     "predictions_per_s": 8192 / d4, "kernel_ms": d4 * 1e3,
