@@ -316,6 +316,19 @@ def main():
                                              "hbm_GBps": bpr * Nv / dv / 1e9,
                                              "hbm_frac": bpr * Nv / dv / 1e9 / PEAK_HBM_GBS}
                 del yv, Hv
+            # the reference's own CPU-runnable case: B = 64 (latency-bound on the GPU: 64 waves /
+            # 2 workgroups on a 256-CU chip)
+            x64, xd64 = x[:64].contiguous(), xd[:64].contiguous()
+            def step64():
+                model(x64, xd64)
+            _w, d64 = timed_loop(step64, 20, 3, False, dev)
+            gm, _sd = make_rnn("gru")
+            def step64g():
+                gm.test_data(x64, 5, dev)
+            _w, d64g = timed_loop(step64g, 20, 3, False, dev)
+            extra["batch_64_latency"] = {"informer_ms": d64 * 1e3, "gru_pred5_ms": d64g * 1e3,
+                                         "informer_predictions_per_s": 64 / d64,
+                                         "gru_predictions_per_s": 64 / d64g}
             for kind in ("lstm", "gru", "rnn"):
                 rm, _sd = make_rnn(kind)
                 nb, _ = synth.channel_histories(8192, seed=1)

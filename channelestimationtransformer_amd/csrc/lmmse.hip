@@ -50,44 +50,66 @@ struct Gram {
 };
 
 // One receive antenna's contribution. WEIGHTED: row scaled by w = 1/S_r (diagonal S).
+// gram_row_h: the Gram matrix part, gram_row_b: the matched-filter part; gram_row: both.
 template <int NS, bool WEIGHTED>
-__device__ inline void gram_row(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS],
-                                float yr, float yi, float w) {
-  float ar[NS], ai[NS];  // (weighted) conj-side operand
+__device__ inline void gram_row_h(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS], float w) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    ar[s] = WEIGHTED ? hr[s] * w : hr[s];
-    ai[s] = WEIGHTED ? hi[s] * w : hi[s];
-  }
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    g.diag[s] = fmaf(ar[s], hr[s], g.diag[s]);
-    g.diag[s] = fmaf(ai[s], hi[s], g.diag[s]);
-    g.br[s] = fmaf(ar[s], yr, g.br[s]);
-    g.br[s] = fmaf(ai[s], yi, g.br[s]);
-    g.bi[s] = fmaf(ar[s], yi, g.bi[s]);
-    g.bi[s] = fmaf(-ai[s], yr, g.bi[s]);
+    const float ar = WEIGHTED ? hr[s] * w : hr[s], ai = WEIGHTED ? hi[s] * w : hi[s];
+    g.diag[s] = fmaf(ar, hr[s], g.diag[s]);
+    g.diag[s] = fmaf(ai, hi[s], g.diag[s]);
 #pragma unroll
     for (int s2 = s + 1; s2 < NS; ++s2) {
       const int p = pair_index(NS, s, s2);
-      g.offr[p] = fmaf(ar[s], hr[s2], g.offr[p]);
-      g.offr[p] = fmaf(ai[s], hi[s2], g.offr[p]);
-      g.offi[p] = fmaf(ar[s], hi[s2], g.offi[p]);
-      g.offi[p] = fmaf(-ai[s], hr[s2], g.offi[p]);
+      g.offr[p] = fmaf(ar, hr[s2], g.offr[p]);
+      g.offr[p] = fmaf(ai, hi[s2], g.offr[p]);
+      g.offi[p] = fmaf(ar, hi[s2], g.offi[p]);
+      g.offi[p] = fmaf(-ai, hr[s2], g.offi[p]);
     }
   }
 }
+template <int NS, bool WEIGHTED>
+__device__ inline void gram_row_b(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS],
+                                  float yr, float yi, float w) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const float ar = WEIGHTED ? hr[s] * w : hr[s], ai = WEIGHTED ? hi[s] * w : hi[s];
+    g.br[s] = fmaf(ar, yr, g.br[s]);
+    g.br[s] = fmaf(ai, yi, g.br[s]);
+    g.bi[s] = fmaf(ar, yi, g.bi[s]);
+    g.bi[s] = fmaf(-ai, yr, g.bi[s]);
+  }
+}
+template <int NS, bool WEIGHTED>
+__device__ inline void gram_row(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS],
+                                float yr, float yi, float w) {
+  gram_row_h<NS, WEIGHTED>(g, hr, hi, w);
+  gram_row_b<NS, WEIGHTED>(g, hr, hi, yr, yi, w);
+}
 
-// Solves (G + lam*I) z = b by Cholesky and forms x_hat / no_eff (see the file header).
+// (G + lam*I)^-1 through its Cholesky factor: W = L^-1 (lower triangular), and per stream
+// rd = 1 / d = 1 / (1 - t), ne = no_eff = t / (1 - t) with t = lam * (A^-1)_ss (file header).
 template <int NS>
-__device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS],
-                                   float (&xi)[NS], float (&ne)[NS]) {
+struct Factor {
+  float Wr[NS][NS], Wi[NS][NS];
+  float rd[NS], ne[NS];
+};
+
+template <int NS>
+__device__ inline void lmmse_factor(const Gram<NS>& g, float lam, Factor<NS>& f) {
+  // Every multiply-add is written as the fma it should be and nothing else may be fused: which
+  // operands the optimiser would contract depends on the surrounding code, and the kernels that
+  // share this function must agree bit for bit.
+#pragma clang fp contract(off)
   float Lr[NS][NS], Li[NS][NS], inv[NS];
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     float d = g.diag[j] + lam;
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= Lr[j][k] * Lr[j][k] + Li[j][k] * Li[j][k];
+    for (int k = 0; k < j; ++k) {
+      d = fmaf(-Lr[j][k], Lr[j][k], d);
+      d = fmaf(-Li[j][k], Li[j][k], d);
+    }
     inv[j] = __builtin_amdgcn_rsqf(d);  // 1 ulp
     Lr[j][j] = d * inv[j];
     Li[j][j] = 0.f;
@@ -96,61 +118,95 @@ __device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS]
       const int p = pair_index(NS, j, i);
       float sr = g.offr[p], si = -g.offi[p];  // A_ij = conj(A_ji), i > j
 #pragma unroll
-      for (int k = 0; k < j; ++k) {
-        sr -= Lr[i][k] * Lr[j][k] + Li[i][k] * Li[j][k];
-        si -= Li[i][k] * Lr[j][k] - Lr[i][k] * Li[j][k];
+      for (int k = 0; k < j; ++k) {  // s -= L_ik conj(L_jk)
+        sr = fmaf(-Lr[i][k], Lr[j][k], sr);
+        sr = fmaf(-Li[i][k], Li[j][k], sr);
+        si = fmaf(-Li[i][k], Lr[j][k], si);
+        si = fmaf(Lr[i][k], Li[j][k], si);
       }
       Lr[i][j] = sr * inv[j];
       Li[i][j] = si * inv[j];
     }
   }
-  // W = L^-1 (lower triangular)
-  float Wr[NS][NS], Wi[NS][NS];
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
-    Wr[j][j] = inv[j];
-    Wi[j][j] = 0.f;
+    f.Wr[j][j] = inv[j];
+    f.Wi[j][j] = 0.f;
 #pragma unroll
     for (int i = j + 1; i < NS; ++i) {
       float sr = 0.f, si = 0.f;
 #pragma unroll
-      for (int k = j; k < i; ++k) {
-        sr += Lr[i][k] * Wr[k][j] - Li[i][k] * Wi[k][j];
-        si += Lr[i][k] * Wi[k][j] + Li[i][k] * Wr[k][j];
+      for (int k = j; k < i; ++k) {  // s += L_ik W_kj
+        sr = fmaf(Lr[i][k], f.Wr[k][j], sr);
+        sr = fmaf(-Li[i][k], f.Wi[k][j], sr);
+        si = fmaf(Lr[i][k], f.Wi[k][j], si);
+        si = fmaf(Li[i][k], f.Wr[k][j], si);
       }
-      Wr[i][j] = -sr * inv[i];
-      Wi[i][j] = -si * inv[i];
+      f.Wr[i][j] = -sr * inv[i];
+      f.Wi[i][j] = -si * inv[i];
     }
   }
-  // u = W b
-  float ur[NS], ui[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float a = 0.f;  // (A^-1)_ss = sum_k |W_ks|^2
+#pragma unroll
+    for (int k = s; k < NS; ++k) {
+      a = fmaf(f.Wr[k][s], f.Wr[k][s], a);
+      a = fmaf(f.Wi[k][s], f.Wi[k][s], a);
+    }
+    const float t = lam * a;
+    f.rd[s] = __builtin_amdgcn_rcpf(1.0f - t);  // 1 ulp
+    f.ne[s] = t * f.rd[s];
+  }
+}
+
+// x_hat = diag(1/d) W^H W b for the matched-filter output b = H^H S^-1 y.
+template <int NS>
+__device__ inline void lmmse_apply(const Factor<NS>& f, const float (&br)[NS], const float (&bi)[NS],
+                                   float (&xr)[NS], float (&xi)[NS]) {
+#pragma clang fp contract(off)
+  float ur[NS], ui[NS];  // u = W b
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     float sr = 0.f, si = 0.f;
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
-      sr += Wr[i][j] * g.br[j] - Wi[i][j] * g.bi[j];
-      si += Wr[i][j] * g.bi[j] + Wi[i][j] * g.br[j];
+      sr = fmaf(f.Wr[i][j], br[j], sr);
+      si = fmaf(f.Wr[i][j], bi[j], si);
+      if (j < i) {  // the diagonal of W is real
+        sr = fmaf(-f.Wi[i][j], bi[j], sr);
+        si = fmaf(f.Wi[i][j], br[j], si);
+      }
     }
     ur[i] = sr;
     ui[i] = si;
   }
-  // z = W^H u ; (A^-1)_ss = sum_k |W_ks|^2
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    float zr = 0.f, zi = 0.f, a = 0.f;
+  for (int s = 0; s < NS; ++s) {  // z = W^H u
+    float zr = 0.f, zi = 0.f;
 #pragma unroll
     for (int k = s; k < NS; ++k) {
-      zr += Wr[k][s] * ur[k] + Wi[k][s] * ui[k];
-      zi += Wr[k][s] * ui[k] - Wi[k][s] * ur[k];
-      a += Wr[k][s] * Wr[k][s] + Wi[k][s] * Wi[k][s];
+      zr = fmaf(f.Wr[k][s], ur[k], zr);
+      zi = fmaf(f.Wr[k][s], ui[k], zi);
+      if (k > s) {
+        zr = fmaf(f.Wi[k][s], ui[k], zr);
+        zi = fmaf(-f.Wi[k][s], ur[k], zi);
+      }
     }
-    const float t = lam * a;
-    const float rd = __builtin_amdgcn_rcpf(1.0f - t);  // 1 ulp
-    xr[s] = zr * rd;
-    xi[s] = zi * rd;
-    ne[s] = t * rd;
+    xr[s] = zr * f.rd[s];
+    xi[s] = zi * f.rd[s];
   }
+}
+
+// Solves (G + lam*I) z = b by Cholesky and forms x_hat / no_eff (see the file header).
+template <int NS>
+__device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS],
+                                   float (&xi)[NS], float (&ne)[NS]) {
+  Factor<NS> f;
+  lmmse_factor<NS>(g, lam, f);
+  lmmse_apply<NS>(f, g.br, g.bi, xr, xi);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) ne[s] = f.ne[s];
 }
 
 // Epilogue of the LLR entry point: exact ("app") log-likelihood ratios ln(P(b=1)/P(b=0)) of
@@ -493,6 +549,303 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Block fading with a shared factorisation (scalar noise): one channel matrix per `hs`
+// consecutive REs. A wave owns a tile of T blocks. Its work is a sequence of equally sized
+// stages that pass through the wave's one LDS buffer: stage 0 of a tile brings the T matrices
+// (H_TILE bytes), which go to registers and are factorised once (Gram, Cholesky, W = L^-1,
+// no_eff); every further stage brings the received vectors of GS = NS symbols of the T blocks
+// (the same number of bytes), and each symbol costs a matched filter b = H^H y plus two
+// triangular products. As in lmmse_tiled a stage is copied to registers and the buffer handed
+// back to the DMA engine at once, so a wave always has a stage in flight. HBM traffic per RE:
+// y + x_hat + no_eff + (H / hs). The arithmetic is that of the per-RE kernels in the same
+// order, so the results are the same bit for bit.
+// CET_BLOCK_ABLATE: timing experiments only (results invalid): bit 0 no result stores, bit 1 a
+// quarter of the matched filter.
+#ifndef CET_BLOCK_ABLATE
+#define CET_BLOCK_ABLATE 0
+#endif
+template <int NR, int NS, int LPR>
+__global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
+                                                  const float* __restrict__ H, float lam,
+                                                  float* __restrict__ x_hat,
+                                                  float* __restrict__ no_eff, long N, int hs,
+                                                  long n_blocks, long n_tiles) {
+  constexpr int T = 64 / LPR;             // blocks per tile
+  constexpr int HB = NR * NS * 8;         // bytes of H per block
+  constexpr int YB = NR * 8;              // bytes of y per RE
+  constexpr int CH = HB / 16, CY = YB / 16;
+  constexpr int H_TILE = T * HB, Y_SYM = T * YB;
+  constexpr int GS = NS;                  // symbols per y stage: GS * Y_SYM == H_TILE
+  constexpr int H_INSTR = H_TILE / 1024, YS_INSTR = Y_SYM / 1024;
+  constexpr int RPP = NR / LPR;
+  static_assert(H_TILE % 1024 == 0 && Y_SYM % 1024 == 0, "stages are whole DMA instructions");
+  static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
+
+  __shared__ __attribute__((aligned(16))) char smem[H_TILE];
+
+  const int lane = threadIdx.x;
+  const int t = lane & (T - 1);  // block within the tile
+  const int p = lane / T;        // which slice of the receive antennas
+  const bool llr_mode = no_eff == nullptr;
+
+  // Symbols a tile works on: those of its first block (every block but the very last one of the
+  // array is complete).
+  auto symbols_of = [&](long tile) {
+    const long left = N - tile * T * hs;  // REs from the tile's first block on (> 0)
+    return left < hs ? (int)left : hs;
+  };
+
+  // stage st of a tile: 0 = the matrices, g + 1 = symbols g*GS .. of every block
+  auto issue = [&](long tile, int st) {
+    const unsigned dst = lds_address(smem);
+    const long blk0 = tile * T;
+    const int kmax = symbols_of(tile);
+    if (st == 0) {
+#pragma unroll
+      for (int i = 0; i < H_INSTR; ++i) {
+        const int P = i * 64 + lane;
+        const int tt = P / CH, q = P % CH;
+        long blk = blk0 + tt;
+        blk = blk < n_blocks ? blk : n_blocks - 1;  // tail tile: re-read the last block
+        dma16(reinterpret_cast<const char*>(H) + blk * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4),
+              dst + i * 1024);
+      }
+    } else {
+      const int k0 = (st - 1) * GS;
+#pragma unroll
+      for (int j = 0; j < GS; ++j) {
+        if (k0 + j < kmax) {
+#pragma unroll
+          for (int i = 0; i < YS_INSTR; ++i) {
+            const int P = i * 64 + lane;
+            const int tt = P / CY, q = P % CY;
+            long re = (blk0 + tt) * hs + k0 + j;
+            re = re < N ? re : N - 1;  // ragged end: results of these lanes are not stored
+            dma16(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
+                  dst + (j * YS_INSTR + i) * 1024);
+          }
+        }
+      }
+    }
+  };
+
+  constexpr int HV = NS == 1 ? RPP / 2 : RPP * (NS / 2);
+  float4 hreg[HV];            // this lane's rows of its block's matrix, for the whole tile
+  float4 yreg[GS][RPP / 2];   // this lane's antennas of the stage's symbols
+  Factor<NS> f;
+  const int swh = chunk_swizzle<CH>(t), swy = chunk_swizzle<CY>(t);
+
+  auto h_rows = [&](int rr, float (&hr)[2][NS], float (&hi)[2][NS]) {
+    if (NS == 1) {
+      const float4 hv = hreg[rr / 2];
+      hr[0][0] = hv.x; hi[0][0] = hv.y; hr[1][0] = hv.z; hi[1][0] = hv.w;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < NS / 2; ++j) {
+          const float4 hv = hreg[(rr + a) * (NS / 2) + j];
+          hr[a][2 * j] = hv.x; hi[a][2 * j] = hv.y;
+          hr[a][2 * j + 1] = hv.z; hi[a][2 * j + 1] = hv.w;
+        }
+    }
+  };
+
+  auto copy_matrices = [&]() {
+    const char* hsrc = smem + t * HB;
+#pragma unroll
+    for (int rr = 0; rr < RPP; rr += 2) {
+      const int r = p * RPP + rr;
+      if (NS == 1) {
+        hreg[rr / 2] = *reinterpret_cast<const float4*>(hsrc + (((r >> 1) ^ swh) << 4));
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int j = 0; j < NS / 2; ++j) {
+            const int c = (r + a) * (NS / 2) + j;
+            hreg[(rr + a) * (NS / 2) + j] = *reinterpret_cast<const float4*>(hsrc + ((c ^ swh) << 4));
+          }
+      }
+    }
+  };
+  auto copy_symbols = [&](int nsym) {
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+      if (j < nsym) {
+        const char* ysrc = smem + j * Y_SYM + t * YB;
+#pragma unroll
+        for (int rr = 0; rr < RPP; rr += 2) {
+          const int r = p * RPP + rr;
+          yreg[j][rr / 2] = *reinterpret_cast<const float4*>(ysrc + (((r >> 1) ^ swy) << 4));
+        }
+      }
+    }
+  };
+
+  auto factorise = [&]() {
+    Gram<NS> g;
+    g.clear();
+#pragma unroll
+    for (int rr = 0; rr < RPP; rr += 2) {
+      float hr[2][NS], hi[2][NS];
+      h_rows(rr, hr, hi);
+      gram_row_h<NS, false>(g, hr[0], hi[0], 1.0f);
+      gram_row_h<NS, false>(g, hr[1], hi[1], 1.0f);
+    }
+#pragma unroll
+    for (int off = T; off < 64; off <<= 1) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) g.diag[s] += __shfl_xor(g.diag[s], off);
+#pragma unroll
+      for (int i = 0; i < Gram<NS>::NP; ++i) {
+        g.offr[i] += __shfl_xor(g.offr[i], off);
+        g.offi[i] += __shfl_xor(g.offi[i], off);
+      }
+    }
+    lmmse_factor<NS>(g, lam, f);
+  };
+
+  // Store instructions per symbol when every lane is in range.
+  constexpr int ST_X = (LPR == 2 && NS == 4) ? 1 : (NS % 2 == 0 ? NS / 2 : NS);
+  auto equalise = [&](long tile, int k0, int nsym) {
+#pragma unroll
+    for (int j = 0; j < GS; ++j) {
+      if (j >= nsym) break;
+      Gram<NS> g;
+      g.clear();
+#pragma unroll
+      for (int rr = 0; rr < ((CET_BLOCK_ABLATE & 2) ? 2 : RPP); rr += 2) {
+        const float4 yv = yreg[j][rr / 2];
+        float hr[2][NS], hi[2][NS];
+        h_rows(rr, hr, hi);
+        gram_row_b<NS, false>(g, hr[0], hi[0], yv.x, yv.y, 1.0f);
+        gram_row_b<NS, false>(g, hr[1], hi[1], yv.z, yv.w, 1.0f);
+      }
+#pragma unroll
+      for (int off = T; off < 64; off <<= 1) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          g.br[s] += __shfl_xor(g.br[s], off);
+          g.bi[s] += __shfl_xor(g.bi[s], off);
+        }
+      }
+      float xr[NS], xi[NS], ne[NS];
+      lmmse_apply<NS>(f, g.br, g.bi, xr, xi);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ne[s] = f.ne[s];
+      if (llr_mode) to_llr<NS>(xr, xi, ne);
+      const long blk = tile * T + t;
+      const long re = blk * hs + k0 + j;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      // plain (cacheable) stores: a store instruction covers 16-byte pieces of many lines, which
+      // the L2 merges with the pieces of the block's other symbols before they go to HBM
+      // (nontemporal stores of such pieces halve the kernel's rate)
+      if (blk < n_blocks && re < N && !(CET_BLOCK_ABLATE & 1)) {
+        if (LPR == 2 && NS == 4) {
+          constexpr int S2 = NS >= 4 ? 2 : 0, S3 = NS >= 4 ? 3 : 0;
+          const v4f xv = p ? v4f{xr[S2], xi[S2], xr[S3], xi[S3]} : v4f{xr[0], xi[0], xr[NS > 1 ? 1 : 0], xi[NS > 1 ? 1 : 0]};
+          const v2f nv = p ? v2f{ne[S2], ne[S3]} : v2f{ne[0], ne[NS > 1 ? 1 : 0]};
+          *reinterpret_cast<v4f*>(x_hat + (re * NS + 2 * p) * 2) = xv;
+          if (!llr_mode) *reinterpret_cast<v2f*>(no_eff + re * NS + 2 * p) = nv;
+        } else if (p == 0) {
+          float* xd = x_hat + re * NS * 2;
+          if (NS % 2 == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; s += 2)
+              *reinterpret_cast<v4f*>(xd + 2 * s) = v4f{xr[s], xi[s], xr[s + 1], xi[s + 1]};
+          } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<v2f*>(xd + 2 * s) = v2f{xr[s], xi[s]};
+          }
+          if (!llr_mode) {
+            float* nd = no_eff + re * NS;
+            if (NS == 4) {
+              *reinterpret_cast<v4f*>(nd) =
+                  v4f{ne[0], ne[NS > 1 ? 1 : 0], ne[NS > 2 ? 2 : 0], ne[NS > 3 ? 3 : 0]};
+            } else if (NS == 2) {
+              *reinterpret_cast<v2f*>(nd) = v2f{ne[0], ne[NS > 1 ? 1 : 0]};
+            } else {
+              *nd = ne[0];
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // Stage pipeline. vmcnt retires vector-memory instructions in issue order; the instructions
+  // younger than the DMA of the stage being waited for are the stores of the stage before it
+  // (none after a matrix stage), which the wait leaves outstanding: waiting for them as well
+  // would stall every stage for a store round trip. `younger` is a lower bound of their number:
+  // exact for a tile whose T blocks are all complete (every lane stores in every instruction),
+  // 1 otherwise (a store whose lanes are all out of range is branched over; the tile's first
+  // block and a stage's first symbol always exist).
+  long tile = blockIdx.x;
+  int st = 0, younger = 0;
+  if (tile < n_tiles) issue(tile, 0);
+  while (tile < n_tiles) {
+    if (CET_BLOCK_ABLATE & 1) younger = 0;
+    switch (younger) {  // the wait count is an immediate
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<1>(); break;
+      case 2: wait_vmcnt<2>(); break;
+      case 3: wait_vmcnt<3>(); break;
+      case 4: wait_vmcnt<4>(); break;
+      case 5: wait_vmcnt<5>(); break;
+      case 6: wait_vmcnt<6>(); break;
+      case 7: wait_vmcnt<7>(); break;
+      default: wait_vmcnt<8>(); break;
+    }
+    const int kmax = symbols_of(tile);
+    const int n_here = 1 + (kmax + GS - 1) / GS;  // stages of this tile
+    const int k0 = (st - 1) * GS;
+    const int nsym = st == 0 ? 0 : (kmax - k0 < GS ? kmax - k0 : GS);
+    if (st == 0) copy_matrices();
+    else copy_symbols(nsym);
+    long ntile = tile;
+    int nst = st + 1;
+    if (nst >= n_here) {
+      nst = 0;
+      ntile = tile + gridDim.x;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ntile < n_tiles) issue(ntile, nst);
+    if (st == 0) {
+      factorise();
+      younger = 0;
+    } else {
+      equalise(tile, k0, nsym);
+      const bool full_tile = (tile * T + T) * hs <= N;
+      younger = full_tile ? nsym * (ST_X + (llr_mode ? 0 : 1)) : 1;
+    }
+    tile = ntile;
+    st = nst;
+  }
+}
+
+template <int NR, int NS, int LPR>
+int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, float* no_eff,
+                 long N, int hshare, hipStream_t stream) {
+  constexpr int T = 64 / LPR;
+  const long n_blocks = (N + hshare - 1) / hshare;
+  const long n_tiles = (n_blocks + T - 1) / T;
+  int dev = 0, cus = 256;
+  CET_HIP(hipGetDevice(&dev));
+  CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  constexpr int LDS_BYTES = T * NR * NS * 8;
+  int per_cu = (160 * 1024) / LDS_BYTES;
+  if (per_cu > 8) per_cu = 8;
+  long grid = (long)cus * per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL((lmmse_block<NR, NS, LPR>), dim3((unsigned)grid), dim3(64), 0, stream, y, H,
+                     no_scalar, x_hat, no_eff, N, hshare, n_blocks, n_tiles);
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+
 template <int NR, int NS, int LPR>
 int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
                  float* x_hat, float* no_eff, long N, int hshare, hipStream_t stream) {
@@ -555,6 +908,12 @@ int dispatch(const float* y, const float* H, int no_mode, float no_scalar, const
     const char* e = getenv("CET_LMMSE_LPR");  // timing experiments only
     return e ? atoi(e) : 0;
   }();
+  // block fading with scalar noise: shared factorisation, unless CET_LMMSE_BLOCK=gather asks for
+  // the per-RE kernel with gathered matrices (the cross-check of the two)
+  const char* blk_env = getenv("CET_LMMSE_BLOCK");  // read per call: tests switch it
+  const bool gather = blk_env && blk_env[0] == 'g';
+  if (hshare > 1 && no_mode == CET_NO_SCALAR && !gather)
+    return launch_block<NR, NS, LPR>(y, H, no_scalar, x_hat, no_eff, N, hshare, stream);
   if (LPR == 2 && lpr_override == 1)
     return launch_tiled<NR, NS, 1>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);
   return launch_tiled<NR, NS, LPR>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);

@@ -174,11 +174,17 @@ def test_ls_estimator_nearest_neighbour(oracle):
 @pytest.mark.parametrize("Nr,Ns", [(16, 4), (8, 4), (4, 2), (2, 1)])
 @pytest.mark.parametrize("N,h_share", [(14 * 300, 14), (14 * 300 - 5, 14), (4099, 3), (1000, 1000),
                                        (77, 2000), (64, 1)])
-def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, oracle):
+@pytest.mark.parametrize("kernel", ["shared_factorisation", "gather"])
+def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, kernel, oracle, monkeypatch):
     """One channel matrix held over h_share consecutive resource elements (a predicted slot):
     the block-fading entry points must return, bit for bit, what the per-element entry points
     return on the expanded H — ragged last block, ragged last tile, every noise mode, the fused
-    demapper — and the float64 checker's values within the usual tolerance."""
+    demapper — and the float64 checker's values within the usual tolerance. Two kernels serve
+    the entry points: one factorises each matrix once and applies it to the block's symbols
+    (scalar noise), the other is the per-element kernel gathering its matrix (other noise
+    modes; CET_LMMSE_BLOCK=gather selects it for scalar noise too)."""
+    if kernel == "gather":
+        monkeypatch.setenv("CET_LMMSE_BLOCK", "gather")
     nb = -(-N // h_share)
     y, _, _ = synth.lmmse_problem(N, Nr, Ns, 0.1, seed=N + Nr + h_share)
     _, Hb, _ = synth.lmmse_problem(nb, Nr, Ns, 0.1, seed=7 * N + Ns)
