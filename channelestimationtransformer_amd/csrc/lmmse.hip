@@ -312,8 +312,14 @@ __device__ inline void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifndef CET_TILED_WPS
+#define CET_TILED_WPS(NR, NS, LPR) (((NR) * (NS) >= 64 && (LPR) == 1) ? 1 : 2)
+#endif
+// Two waves per SIMD (8 per CU): the register budget is stated, or the allocator spreads out
+// beyond 256 registers and halves the number of tiles in flight. The one-lane-per-RE variant of
+// the largest shape holds a whole 16x4 matrix per lane and does not fit that budget.
 template <int NR, int NS, int LPR, bool PER_RE_NOISE>
-__global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
+__global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(const float* __restrict__ y,
                                                   const float* __restrict__ H, float no_scalar,
                                                   const float* __restrict__ no_dev,
                                                   float* __restrict__ x_hat,
@@ -565,6 +571,8 @@ __global__ __launch_bounds__(64) void lmmse_tiled(const float* __restrict__ y,
 #ifndef CET_BLOCK_ABLATE
 #define CET_BLOCK_ABLATE 0
 #endif
+// One wave per SIMD for the large shapes: the matrices, a stage of received vectors and the
+// factor live in registers (about 300 of the 512 a lone wave may use).
 template <int NR, int NS, int LPR>
 __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
                                                   const float* __restrict__ H, float lam,
@@ -743,7 +751,8 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
       // plain (cacheable) stores: a store instruction covers 16-byte pieces of many lines, which
       // the L2 merges with the pieces of the block's other symbols before they go to HBM
       // (nontemporal stores of such pieces halve the kernel's rate)
-      if (blk < n_blocks && re < N && !(CET_BLOCK_ABLATE & 1)) {
+      // (ablation bit 0: a condition the compiler cannot fold keeps the arithmetic alive)
+      if (blk < n_blocks && re < N && (!(CET_BLOCK_ABLATE & 1) || lam < -1.0f)) {
         if (LPR == 2 && NS == 4) {
           constexpr int S2 = NS >= 4 ? 2 : 0, S3 = NS >= 4 ? 3 : 0;
           const v4f xv = p ? v4f{xr[S2], xi[S2], xr[S3], xi[S3]} : v4f{xr[0], xi[0], xr[NS > 1 ? 1 : 0], xi[NS > 1 ? 1 : 0]};
