@@ -571,6 +571,11 @@ __global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(co
 #ifndef CET_BLOCK_ABLATE
 #define CET_BLOCK_ABLATE 0
 #endif
+// A stage of received vectors is CET_BLOCK_GM times the size of the matrix stage. 2 (eight
+// symbols of 16x4 in registers) spills and halves the rate.
+#ifndef CET_BLOCK_GM
+#define CET_BLOCK_GM 1
+#endif
 // One wave per SIMD for the large shapes: the matrices, a stage of received vectors and the
 // factor live in registers (about 300 of the 512 a lone wave may use).
 template <int NR, int NS, int LPR>
@@ -584,13 +589,13 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   constexpr int YB = NR * 8;              // bytes of y per RE
   constexpr int CH = HB / 16, CY = YB / 16;
   constexpr int H_TILE = T * HB, Y_SYM = T * YB;
-  constexpr int GS = NS;                  // symbols per y stage: GS * Y_SYM == H_TILE
+  constexpr int GS = NS * CET_BLOCK_GM;   // symbols per y stage: GS * Y_SYM == GM * H_TILE
   constexpr int H_INSTR = H_TILE / 1024, YS_INSTR = Y_SYM / 1024;
   constexpr int RPP = NR / LPR;
   static_assert(H_TILE % 1024 == 0 && Y_SYM % 1024 == 0, "stages are whole DMA instructions");
   static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
 
-  __shared__ __attribute__((aligned(16))) char smem[H_TILE];
+  __shared__ __attribute__((aligned(16))) char smem[CET_BLOCK_GM * H_TILE];
 
   const int lane = threadIdx.x;
   const int t = lane & (T - 1);  // block within the tile
@@ -806,7 +811,15 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
       case 5: wait_vmcnt<5>(); break;
       case 6: wait_vmcnt<6>(); break;
       case 7: wait_vmcnt<7>(); break;
-      default: wait_vmcnt<8>(); break;
+      case 8: wait_vmcnt<8>(); break;
+      case 9: wait_vmcnt<9>(); break;
+      case 10: wait_vmcnt<10>(); break;
+      case 11: wait_vmcnt<11>(); break;
+      case 12: wait_vmcnt<12>(); break;
+      case 13: wait_vmcnt<13>(); break;
+      case 14: wait_vmcnt<14>(); break;
+      case 15: wait_vmcnt<15>(); break;
+      default: wait_vmcnt<16>(); break;
     }
     const int kmax = symbols_of(tile);
     const int n_here = 1 + (kmax + GS - 1) / GS;  // stages of this tile
@@ -844,7 +857,7 @@ int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, 
   int dev = 0, cus = 256;
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  constexpr int LDS_BYTES = T * NR * NS * 8;
+  constexpr int LDS_BYTES = CET_BLOCK_GM * T * NR * NS * 8;
   int per_cu = (160 * 1024) / LDS_BYTES;
   if (per_cu > 8) per_cu = 8;
   long grid = (long)cus * per_cu;
