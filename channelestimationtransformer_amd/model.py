@@ -26,8 +26,9 @@ class _DeviceWeights(nn.Module):
     """Keeps one library handle (packed weights on the GPU) per device.
 
     Packing walks the whole state_dict, so it is not repeated per call: the handle is rebuilt
-    only after `load_state_dict`, after `.to()/.cuda()/.float()` style conversions, or when
-    `refresh_weights()` is called (needed after modifying parameters in place)."""
+    only after `load_state_dict`, after `.to()/.cuda()/.float()` style conversions, on leaving
+    training mode (`.eval()` after `.train()`), or when `refresh_weights()` is called (needed
+    after modifying parameters in place while in eval mode)."""
 
     def __init__(self):
         super().__init__()
@@ -44,6 +45,11 @@ class _DeviceWeights(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self._weights_version += 1
         return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode=True):
+        if self.training and not mode:  # leaving training mode: the parameters may have moved
+            self._weights_version += 1
+        return super().train(mode)
 
     def _create(self, device_index):  # -> (handle, extra)
         raise NotImplementedError
@@ -280,8 +286,24 @@ class _RecurrentBase(_DeviceWeights):
         return torch.ops.cet.rnn_rollout(x, self._handle_for(x.device)[0].value, int(pred_len))
 
     def train_data(self, x, device=None):
-        raise NotImplementedError("training (teacher-forced `train_data`) is outside the "
-                                  "inference path this package implements")
+        """Teacher-forced pass used by the reference's training loop (LocalSimulations/models/
+        model.py:285-297, 360-372, 435-447; caller HPC/python/utils.py:191): `[B, seq_len,
+        features]` -> the one-step-ahead output of every step, `[B, seq_len, features]`. Training
+        is not part of the accelerated path: this runs the stock torch modules that hold the
+        parameters (so autograd works, on whatever device `x` and the parameters live), not the
+        HIP rollout kernel."""
+        unit = self.model
+        cell = getattr(unit, self._cell)
+        B = x.shape[0]
+        state = x.new_zeros(self.num_layers, B, self.hidden_size)
+        if self._cell == "lstm":
+            state = (state, state.clone())
+        outputs = []
+        for idx in range(x.shape[1]):
+            step = unit.encoder(x[:, idx:idx + 1].permute(1, 0, 2).contiguous())
+            step, state = cell(step, state)
+            outputs.append(unit.decoder(step))
+        return torch.cat(outputs, dim=0).permute(1, 0, 2).contiguous()
 
 
 class RNN(_RecurrentBase):

@@ -103,3 +103,29 @@ def test_random_shapes_against_checker(cls, F, I, H, layers, oracle):
     want = oracle.rnn_rollout(kind, F, I, H, layers, blobs.pack_rnn(sd, kind, F, I, H, layers), x, 9)
     assert out.shape == want.shape == (45, 9, F)
     assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("name", sorted(RNN_CASES))
+def test_training_step_then_rollout(name, oracle):
+    """`train_data` runs the stock torch modules on the GPU: its last teacher-forced output equals
+    the first prediction of the HIP rollout, and after an optimizer step `.eval()` repacks the
+    weights, so the rollout follows the updated parameters."""
+    _cls, kind, F, I, H, layers = RNN_CASES[name]
+    m = build(name).cuda()
+    x = torch.randn(40, 25, F, generator=torch.Generator().manual_seed(2)).cuda()
+    before = m.test_data(x, 3, "cuda")
+    m.train()
+    tf = m.train_data(x, "cuda")
+    assert (tf[:, -1] - before[:, 0]).abs().max() < 2e-5
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    (tf[:, :-1] - x[:, 1:]).square().mean().backward()
+    opt.step()
+    with pytest.raises(RuntimeError):
+        m.test_data(x, 3, "cuda")  # still in training mode
+    m.eval()
+    after = m.test_data(x, 3, "cuda")
+    assert (after - before).abs().max() > 1e-4
+    blob = blobs.pack_rnn({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()},
+                          kind, F, I, H, layers)
+    want = oracle.rnn_rollout(kind, F, I, H, layers, blob, x.cpu().numpy(), 3)
+    assert np.abs(after.cpu().numpy() - want).max() < 1e-4 * max(1.0, float(np.abs(want).max()))

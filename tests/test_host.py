@@ -126,3 +126,22 @@ def test_antenna_grouping_round_trip():
     assert torch.equal(grouped[8 * 2 + 2 * 3 + 1, :, 2, 1], h[2, :, 4 * 3 + 2, 2 * 1 + 1])
     with pytest.raises(RuntimeError):
         e2e.group_antennas(torch.zeros(1, 2, 6, 4))
+
+
+@pytest.mark.parametrize("name", sorted(RNN_CASES))
+def test_train_data_is_the_teacher_forced_pass(name, oracle):
+    """`train_data` (stock torch modules, autograd) against the checker: its output at step L - 1
+    is the first prediction of a rollout over the first L inputs."""
+    cls, kind, F, I, H, layers = RNN_CASES[name]
+    m = getattr(cet, cls)(F, I, H, layers)
+    sd = sub_dict(load_npz("rnn_ckpt.npz"), name)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    x = torch.randn(3, 9, F, generator=torch.Generator().manual_seed(1))
+    out = m.train_data(x, "cpu")
+    assert out.shape == (3, 9, F) and out.requires_grad
+    blob = blobs.pack_rnn(sd, kind, F, I, H, layers)
+    for L in (1, 4, 9):
+        want = oracle.rnn_rollout(kind, F, I, H, layers, blob, x[:, :L].numpy().copy(), 1)
+        assert np.abs(out[:, L - 1].detach().numpy() - want[:, 0]).max() < 2e-5
+    out.square().mean().backward()
+    assert all(p.grad is not None for p in m.parameters())
