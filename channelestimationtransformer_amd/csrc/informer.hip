@@ -1700,15 +1700,17 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   }
   const size_t wg_wave_bytes = (size_t)wg_rows * LDW * sizeof(float);
   const size_t wg_lds = 2 * WBLK * sizeof(float) + WG_WAVES * wg_wave_bytes;
-  // The workgroup kernel fills a CU with 8 sequences; below about 5 sequences per CU the
-  // one-wave kernel, which spreads single waves over all CUs, finishes sooner.
+  // The workgroup kernel fills a CU with 8 sequences and takes about 0.27 ms per round of
+  // 8 x CUs sequences; the one-wave kernel spreads single waves over all CUs and finishes sooner
+  // as long as every SIMD holds at most one of them (measured: 0.23 vs 0.27 ms at 4 sequences
+  // per CU, 0.32 vs 0.28 ms at 5).
   static int cus = 0;
   if (!cus) {
     int dev = 0;
     CET_HIP(hipGetDevice(&dev));
     CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  const bool wg = wg_lds <= 160 * 1024 && !force_one && (force_wg || B > 5 * cus);
+  const bool wg = wg_lds <= 160 * 1024 && !force_one && (force_wg || B > 4 * cus);
 #ifdef CET_PROF
   static unsigned long long* prof_dev = nullptr;
   const size_t prof_bytes = (size_t)PROF_SAMPLES * PROF_MAXM * sizeof(unsigned long long);

@@ -22,7 +22,7 @@ TOL_ATTN = 2e-5   # attention probabilities (softmax outputs after up to 7 layer
 @pytest.fixture(autouse=True, params=["one_wave", "workgroup", "workgroup_unpacked"])
 def kernel_variant(request, monkeypatch):
     """Every test of this file runs on every Transformer kernel path: the library picks one by
-    batch size (one wave per sequence below ~5 sequences per CU, else 8-wave workgroups with
+    batch size (one wave per sequence up to 4 sequences per CU, else 8-wave workgroups with
     LDS-staged weights, which also pack two short sequences into one tile at the end of the
     encoder stack); CET_INFORMER_KERNEL / CET_INFORMER_PACK pin the choice for a call."""
     monkeypatch.setenv("CET_INFORMER_KERNEL", request.param.split("_")[0] if request.param != "one_wave" else "one_wave")
