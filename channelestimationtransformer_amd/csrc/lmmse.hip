@@ -312,12 +312,14 @@ __device__ inline void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Register budget (waves per SIMD the allocator must leave room for). The shapes with 32 or
+// more matrix entries per RE need a few registers more than the 256 of a two-wave budget; the
+// spills that budget forces cost 7 % extra HBM traffic (scratch) for no gain in rate, so those
+// shapes run one wave per SIMD (4 tiles of 20 KB in flight per CU; the kernel is bound by the
+// read/write mix of the stream, not by the bytes in flight).
 #ifndef CET_TILED_WPS
-#define CET_TILED_WPS(NR, NS, LPR) (((NR) * (NS) >= 64 && (LPR) == 1) ? 1 : 2)
+#define CET_TILED_WPS(NR, NS, LPR) ((NR) * (NS) >= 32 ? 1 : 2)
 #endif
-// Two waves per SIMD (8 per CU): the register budget is stated, or the allocator spreads out
-// beyond 256 registers and halves the number of tiles in flight. The one-lane-per-RE variant of
-// the largest shape holds a whole 16x4 matrix per lane and does not fit that budget.
 template <int NR, int NS, int LPR, bool PER_RE_NOISE>
 __global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(const float* __restrict__ y,
                                                   const float* __restrict__ H, float no_scalar,
@@ -857,9 +859,14 @@ int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, 
   int dev = 0, cus = 256;
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  constexpr int LDS_BYTES = CET_BLOCK_GM * T * NR * NS * 8;
-  int per_cu = (160 * 1024) / LDS_BYTES;
-  if (per_cu > 8) per_cu = 8;
+  // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per CU
+  static int per_cu = 0;
+  if (!per_cu) {
+    int nb = 0;
+    CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nb, reinterpret_cast<const void*>(&lmmse_block<NR, NS, LPR>), 64, 0));
+    per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  }
   long grid = (long)cus * per_cu;
   if (grid > n_tiles) grid = n_tiles;
   hipLaunchKernelGGL((lmmse_block<NR, NS, LPR>), dim3((unsigned)grid), dim3(64), 0, stream, y, H,
@@ -876,10 +883,14 @@ int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, c
   int dev = 0, cus = 256;
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  // resident waves per CU: as many as the LDS staging buffers allow, at most 2 per SIMD
-  constexpr int BUF_BYTES = T * (NR * NS * 8 + NR * 8) + 256;
-  int per_cu = (160 * 1024) / BUF_BYTES;
-  if (per_cu > 8) per_cu = 8;
+  // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per CU
+  static int per_cu = 0;
+  if (!per_cu) {
+    int nb = 0;
+    CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nb, reinterpret_cast<const void*>(&lmmse_tiled<NR, NS, LPR, false>), 64, 0));
+    per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  }
   long grid = (long)cus * per_cu;
   if (grid > n_tiles) grid = n_tiles;
   if (no_mode == CET_NO_SCALAR) {
