@@ -79,7 +79,7 @@ def test_stored_pairs_of_the_reference():
         dec_inp = torch.zeros_like(enc_inp[:, -5:, :])
         dec_inp = torch.cat([enc_inp[:, 25 - 10:25, :], dec_inp], dim=1)
         outputs = m(enc_inp, dec_inp)[0]
-        outputs = cet.real2complex(np.array(outputs.cpu().detach())).reshape([64, 5, 4, 2])
+        outputs = cet.real2complex(outputs.cpu().detach().numpy()).reshape([64, 5, 4, 2])
         assert np.abs(outputs - cr[f"transformer_{tag}"]).max() < TOL_PRED
 
 
@@ -138,6 +138,30 @@ def test_shipped_narrow_checkpoints(name, dm, oracle):
         assert np.abs(a - v[f"{name}/attn_{i}"]).max() < TOL_ATTN, f"{name} attention map {i}"
     out = m.to("cuda")(torch.from_numpy(v[f"{name}/x_enc"]).cuda(), torch.from_numpy(v[f"{name}/x_dec"]).cuda())
     assert np.array_equal(out[0].cpu().numpy(), pred)
+
+
+@pytest.mark.parametrize("name", ["uplink", "multigpu"])
+def test_shipped_hpc_checkpoints(name):
+    """Two more shipped checkpoints (HPC/TrainedTransformers/InformerStack_best_model_params_V30_
+    uplink.pt, best_model_params_V30_MultiGPU.pt), loaded with their stored key names (the
+    `module.` prefix of a DataParallel model), against the imported reference's outputs."""
+    v = load_npz("informer_hpc.npz")
+    m = build("InformerStack", DEFAULT_ARGS, sub_dict(v, f"{name}/sd")).cuda()
+    pred, attns = m(torch.from_numpy(v[f"{name}/x_enc"]).cuda(), torch.from_numpy(v[f"{name}/x_dec"]).cuda())
+    assert np.abs(pred.cpu().numpy() - v[f"{name}/pred"]).max() < TOL_PRED
+    assert np.abs(attns[0][0].cpu().numpy() - v[f"{name}/attn_0"]).max() < TOL_ATTN
+
+
+def test_e2e_class_is_the_same_wiring():
+    """InformerStack_e2e (LocalSimulations/models/model.py:84-158) differs from InformerStack in
+    its training target only: same state_dict keys, same outputs."""
+    ck = dict(load_npz("informer_ckpt.npz"))
+    ref = load_npz("informer_ref.npz")
+    a = build("InformerStack", DEFAULT_ARGS, ck).cuda()
+    b = build("InformerStack_e2e", DEFAULT_ARGS, ck).cuda()
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    x, xd = torch.from_numpy(ref["x_enc"]).cuda(), torch.from_numpy(ref["x_dec"]).cuda()
+    assert torch.equal(a(x, xd)[0], b(x, xd)[0])
 
 
 def test_module_api_and_attention_nesting(oracle):

@@ -125,3 +125,20 @@ def test_checker_on_shipped_narrow_checkpoints(name, dm, oracle):
         assert t.shape[-1] == dm and np.abs(t - v[f"{name}/tap_{i}"]).max() < 2e-5, i
     for i, a in enumerate(attn):
         assert np.abs(a - v[f"{name}/attn_{i}"]).max() < 5e-6, i
+
+
+@pytest.mark.parametrize("name", ["uplink", "multigpu"])
+def test_checker_on_shipped_hpc_checkpoints(name, oracle):
+    """HPC/TrainedTransformers/InformerStack_best_model_params_V30_uplink.pt and
+    best_model_params_V30_MultiGPU.pt, keys as stored (`module.` prefix), on sequences of the
+    reference's CR_data_36 (tests/golden/make_golden_hpc.py)."""
+    from channelestimationtransformer_amd import blobs
+    from conftest import load_npz, sub_dict
+    v = load_npz("informer_hpc.npz")
+    sd = blobs.normalize_state_dict(sub_dict(v, f"{name}/sd"))
+    cfg = blobs.make_informer_cfg(16, 16, 16, 25, 10, 5, 64, 8, 4, 3, 64, True, True, "gelu")
+    blob = blobs.pack_informer(sd, cfg)
+    pred, attn, _ = oracle.informer_forward(cfg, blob, v[f"{name}/x_enc"], v[f"{name}/x_dec"],
+                                            want_attn=True, want_taps=True)
+    assert np.abs(pred - v[f"{name}/pred"]).max() < 5e-6
+    assert np.abs(attn[0] - v[f"{name}/attn_0"]).max() < 5e-6
