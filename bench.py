@@ -1,6 +1,8 @@
 """Throughput benchmark of the predictor + LMMSE inference path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload informer|lmmse|lstm|gru|rnn]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--workload informer|lmmse|lstm|gru|rnn|e2e] [--batch B] [--pred-len P]
+                    [--h-share n] [--geometry reference|scaled] [--no-attention-maps]
 
 One "step" is one pass of the hot path over one batch of synthetic input that is already
 resident in HBM. The default workload is the Transformer predictor forward on 4096 channel
