@@ -356,7 +356,7 @@ def main():
         cr = np.load(os.path.join(GOLDEN, "cr_pairs.npz"))
         real = np.concatenate([cr["data_30"], cr["data_36"], cr["data_60"]])
         real = np.roll(real, 7 * rank, axis=0)[np.arange(S) % real.shape[0]]
-        real = torch.from_numpy(real).to(dev)
+        real = torch.from_numpy(real).to(dev).to(torch.complex64)
         if scaled:  # eight stored 4x2 sequences make one 16x4 subcarrier sample
             real = e2e.ungroup_antennas(real[:S - S % 8], Nr, Nt)
         h_hist, h_future = real[:, :25].contiguous(), real[:, 25:30].contiguous()
@@ -372,9 +372,9 @@ def main():
             else:
                 h_hat = e2e.predict_slots(model, h_hist, 10, 5)
             x_hat, _ = e2e.equalize_slots(h_hat, y, no)
-            holder["sums"] = {"nmse": metrics.nmse_partial_sums(h_hat, h_future),
-                              "bits": metrics.qpsk_bit_errors(x_hat, xs),
-                              "bits_perfect": metrics.qpsk_bit_errors(x_hat, xs)}
+            bits = metrics.qpsk_bit_errors(x_hat, xs)
+            holder["sums"] = {"nmse": metrics.nmse_partial_sums(h_hat, h_future), "bits": bits,
+                              "bits_perfect": bits}  # replaced after the timed region
 
         wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
         # outside the timed region: the same link equalized with the true channel, and with the

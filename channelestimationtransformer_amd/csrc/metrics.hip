@@ -2,7 +2,12 @@
 // They are what a rank contributes to the one all-reduce of an evaluation
 // (HPC/python/Evaluate.py:172-177 forms NMSE_s = sum_err_s / sum_pow_s over batch and antennas;
 // LocalSimulations/EndtoEndtest.py:196-200 counts bit errors). HBM-bound single pass: every
-// input element is read once, reduced in fp64 inside a wave and added with one atomic per wave.
+// input element is read once, reduced in fp64 inside a wave, then across the four waves of a
+// workgroup through LDS, and added with ONE atomic per workgroup and sum: atomics on one address
+// serialise in L2 (8192 of them, one per wave, used to cost 100 us of a 110 us kernel), so the
+// grids are kept to a few hundred workgroups that stride over the data.
+#include <cstdint>
+
 #include "cet_internal.h"
 
 namespace cet {
@@ -12,6 +17,15 @@ __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
+}
+
+// Sum over the 256 threads of a workgroup; the result is valid in thread 0. `slot`: 4 doubles of
+// LDS per quantity reduced.
+__device__ inline double block_sum(double v, double* slot) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return slot[0] + slot[1] + slot[2] + slot[3];
 }
 
 // pred, truth [B][P][C] fp32 (C % 4 == 0). blockIdx.y = slot p. sums[0][p] += sum (t-p)^2,
@@ -35,9 +49,10 @@ __global__ __launch_bounds__(256) void nmse_sums_kernel(const float* __restrict_
     err += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
     pow += (double)t.x * t.x + (double)t.y * t.y + (double)t.z * t.z + (double)t.w * t.w;
   }
-  err = wave_sum(err);
-  pow = wave_sum(pow);
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ double red[8];
+  err = block_sum(err, red);
+  pow = block_sum(pow, red + 4);
+  if (threadIdx.x == 0) {
     atomicAdd(sums + p, err);
     atomicAdd(sums + P + p, pow);
   }
@@ -47,15 +62,29 @@ __global__ __launch_bounds__(256) void nmse_sums_kernel(const float* __restrict_
 // (real > 0, imag > 0), out[1] += 2 N.
 __global__ __launch_bounds__(256) void qpsk_errors_kernel(const float2* __restrict__ x_hat,
                                                           const float2* __restrict__ x_true,
-                                                          double* __restrict__ out, long N) {
-  unsigned cnt = 0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
+                                                          double* __restrict__ out, long N,
+                                                          long n_vec) {
+  // symbols [0, n_vec) two per 16-byte load (n_vec is even, and 0 unless both arrays are 16-byte
+  // aligned), the rest one by one
+  unsigned long long cnt = 0;
+  const float4* a4 = reinterpret_cast<const float4*>(x_hat);
+  const float4* t4 = reinterpret_cast<const float4*>(x_true);
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
+  for (long i = tid; i < n_vec / 2; i += nthr) {
+    const float4 a = a4[i], t = t4[i];
+    cnt += ((a.x > 0.f) != (t.x > 0.f)) + ((a.y > 0.f) != (t.y > 0.f)) +
+           ((a.z > 0.f) != (t.z > 0.f)) + ((a.w > 0.f) != (t.w > 0.f));
+  }
+  for (long i = n_vec + tid; i < N; i += nthr) {
     const float2 a = x_hat[i], t = x_true[i];
     cnt += ((a.x > 0.f) != (t.x > 0.f)) + ((a.y > 0.f) != (t.y > 0.f));
   }
-  const double s = wave_sum((double)cnt);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out + 1, 2.0 * (double)N);
+  __shared__ double red[4];
+  const double s = block_sum((double)cnt, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(out, s);
+    if (blockIdx.x == 0) atomicAdd(out + 1, 2.0 * (double)N);
+  }
 }
 
 }  // namespace
@@ -65,7 +94,7 @@ int nmse_sums_launch(const float* pred, const float* truth, double* sums, long B
   CET_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)P * sizeof(double), stream));
   if (B == 0) return CET_OK;
   long blocks = (B * (C / 4) + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 128) blocks = 128;  // x P slots
   hipLaunchKernelGGL(nmse_sums_kernel, dim3((unsigned)blocks, (unsigned)P), dim3(256), 0, stream, pred,
                      truth, sums, B, P, C);
   CET_HIP(hipGetLastError());
@@ -76,11 +105,14 @@ int qpsk_errors_launch(const float* x_hat, const float* x_true, double* out, lon
                        hipStream_t stream) {
   CET_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), stream));
   if (N == 0) return CET_OK;
-  long blocks = (N + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x_hat) | reinterpret_cast<uintptr_t>(x_true)) & 15) == 0;
+  const long n_vec = aligned ? N / 2 * 2 : 0;
+  long blocks = (N / 2 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(qpsk_errors_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
                      reinterpret_cast<const float2*>(x_hat), reinterpret_cast<const float2*>(x_true),
-                     out, N);
+                     out, N, n_vec);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }

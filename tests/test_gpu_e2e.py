@@ -111,12 +111,16 @@ def test_evaluation_sum_kernels_match_float64():
     got = metrics.nmse_partial_sums(torch.from_numpy(pc).cuda(), torch.from_numpy(tc).cuda()).cpu().numpy()
     want = np.stack([(np.abs(tc.astype(np.complex128) - pc) ** 2).sum((0, 2, 3)), (np.abs(tc.astype(np.complex128)) ** 2).sum((0, 2, 3))])
     assert np.allclose(got, want, rtol=1e-12)
-    for N in (1, 1000, 1 << 20):
+    for N in (1, 2, 1000, 1001, 1 << 20, (1 << 21) + 7):
         xt = ((2 * rng.integers(0, 2, N) - 1) + 1j * (2 * rng.integers(0, 2, N) - 1)).astype(np.complex64)
         xh = (xt + 1.2 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
         got = metrics.qpsk_bit_errors(torch.from_numpy(xh).cuda(), torch.from_numpy(xt).cuda()).cpu().numpy()
         want = ((xh.real > 0) != (xt.real > 0)).sum() + ((xh.imag > 0) != (xt.imag > 0)).sum()
         assert got[0] == want and got[1] == 2 * N
+        if N > 2:  # views that start 8 bytes into their storage: not 16-byte aligned
+            got = metrics.qpsk_bit_errors(torch.from_numpy(xh).cuda()[1:], torch.from_numpy(xt).cuda()[1:]).cpu().numpy()
+            want = ((xh.real > 0) != (xt.real > 0))[1:].sum() + ((xh.imag > 0) != (xt.imag > 0))[1:].sum()
+            assert got[0] == want and got[1] == 2 * (N - 1)
 
 
 def test_device_channel_generator():
