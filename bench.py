@@ -318,6 +318,27 @@ def main():
                                              "hbm_GBps": bpr * Nv / dv / 1e9,
                                              "hbm_frac": bpr * Nv / dv / 1e9 / PEAK_HBM_GBS}
                 del yv, Hv
+            # the reference's receive chain on its own grid (EndtoEndtest.py:50-59, 130-133, 184-191):
+            # LS estimate with nearest-neighbour interpolation -> LMMSEEqualizer object, 4 rx x 2 streams
+            rg = cet.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=1,
+                                  num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                                  dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+            est = cet.LSChannelEstimator(rg, interpolation_type="nn")
+            equ = cet.LMMSEEqualizer(rg, cet.StreamManagement(np.array([[1]]), 2))
+            nb = 8192
+            yg = torch.view_as_complex(torch.randn(nb, 1, 4, 14, 76, 2, device=dev))
+            hold2 = {}
+            def step_ls():
+                hold2["h"], hold2["e"] = est([yg, 0.1])
+            _w, dls = timed_loop(step_ls, 10, 2, False, dev)
+            def step_eq():
+                equ([yg, hold2["h"], hold2["e"], 0.1])
+            _w, deq = timed_loop(step_eq, 10, 2, False, dev)
+            n_out = nb * 4 * 2 * 14 * 64
+            extra["receive_chain_reference_grid"] = {
+                "batch": nb, "ls_nn_ms": dls * 1e3, "ls_nn_GBps": (n_out * 12 + yg.numel() * 8) / dls / 1e9,
+                "equalizer_object_ms": deq * 1e3, "equalizer_object_REs_per_s": nb * 12 * 64 / deq}
+            del yg, hold2
             # the reference's own CPU-runnable case: B = 64 (latency-bound on the GPU: 64 waves /
             # 2 workgroups on a 256-CU chip)
             x64, xd64 = x[:64].contiguous(), xd[:64].contiguous()
