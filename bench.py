@@ -337,7 +337,9 @@ def main():
             n_out = nb * 4 * 2 * 14 * 64
             extra["receive_chain_reference_grid"] = {
                 "batch": nb, "ls_nn_ms": dls * 1e3, "ls_nn_GBps": (n_out * 12 + yg.numel() * 8) / dls / 1e9,
-                "equalizer_object_ms": deq * 1e3, "equalizer_object_REs_per_s": nb * 12 * 64 / deq}
+                "equalizer_object_ms": deq * 1e3, "equalizer_object_REs_per_s": nb * 12 * 64 / deq,
+                # per data RE: y 4x8 + h_hat 8x8 + err_var 8x4 + x_hat 2x8 + no_eff 2x4 bytes
+                "equalizer_object_GBps": nb * 12 * 64 * 152.0 / deq / 1e9}
             del yg, hold2
             # the reference's own CPU-runnable case: B = 64 (latency-bound on the GPU: 64 waves /
             # 2 workgroups on a 256-CU chip)

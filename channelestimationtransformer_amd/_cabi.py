@@ -19,7 +19,7 @@ EXPORTS = (
     "cet_informer_blob_size", "cet_informer_create", "cet_informer_attn_size",
     "cet_informer_forward", "cet_informer_taps_size", "cet_informer_forward_taps",
     "cet_rnn_blob_size", "cet_rnn_create", "cet_rnn_rollout", "cet_lmmse", "cet_lmmse_direct",
-    "cet_lmmse_llr", "cet_lmmse_block", "cet_lmmse_block_llr", "cet_ls_nn", "cet_nmse_sums", "cet_qpsk_bit_errors",
+    "cet_lmmse_llr", "cet_lmmse_block", "cet_lmmse_block_llr", "cet_lmmse_grid", "cet_ls_nn", "cet_nmse_sums", "cet_qpsk_bit_errors",
 )
 
 
@@ -76,6 +76,8 @@ def lib():
                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.cet_lmmse_block_llr.argtypes = [fp, fp, ctypes.c_int, ctypes.c_float, fp, fp, ctypes.c_long,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.cet_lmmse_grid.argtypes = [fp, fp, fp, ctypes.c_int, ctypes.c_float, fp, fp, fp, fp, fp] + \
+        [ctypes.c_int] * 7 + [vp]
     L.cet_ls_nn.argtypes = [fp, fp, fp, fp, ctypes.c_float, fp, fp, ctypes.c_long, ctypes.c_int,
                             ctypes.c_int, vp]
     L.cet_nmse_sums.argtypes = [fp, fp, fp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp]

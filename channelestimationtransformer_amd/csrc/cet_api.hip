@@ -193,6 +193,24 @@ int cet_lmmse_block_llr(const float* y, const float* H, int no_mode, float no_sc
                        stream);
 }
 
+int cet_lmmse_grid(const float* y, const float* h_hat, const float* err_var, int no_mode,
+                   float no_scalar, const float* no_dev, const int32_t* data_sym,
+                   const int32_t* eff_sc, float* x_hat, float* no_eff, int B, int Nr, int Ns,
+                   int n_sym, int fft, int n_sc, int n_ds, void* stream) {
+  if (B < 0 || Nr <= 0 || Ns <= 0 || n_sym < 1 || fft < 1 || n_sc < 0 || n_sc > fft || n_ds < 0 ||
+      n_ds > n_sym)
+    return CET_ERR_INVALID_ARG;
+  if (no_mode < 0 || no_mode > 2) return CET_ERR_INVALID_ARG;
+  if ((long)B * n_sc * n_ds == 0) return CET_OK;
+  if (!y || !h_hat || !data_sym || !eff_sc || !x_hat || !no_eff) return CET_ERR_INVALID_ARG;
+  if (no_mode != 0 && !no_dev) return CET_ERR_INVALID_ARG;
+  if (no_mode == 0 && !(no_scalar > 0.f) && !err_var) return CET_ERR_INVALID_ARG;
+  if (Ns > Nr) return CET_ERR_UNSUPPORTED;
+  return lmmse_grid_launch(y, h_hat, err_var, no_mode, no_scalar, no_dev, data_sym, eff_sc, x_hat,
+                           no_eff, B, Nr, Ns, n_sym, fft, n_sc, n_ds,
+                           static_cast<hipStream_t>(stream));
+}
+
 int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float* pabs2inv,
               float no, float* h_hat, float* err_var, long planes, int plane, int T, void* stream) {
   if (planes < 0 || plane < 1 || T < 1 || !(no >= 0.f)) return CET_ERR_INVALID_ARG;

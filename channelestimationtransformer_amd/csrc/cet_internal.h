@@ -28,6 +28,11 @@ int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, c
                  float* x_hat, float* no_eff, long N, int Nr, int Ns, int hshare, int variant,
                  hipStream_t stream);
 
+int lmmse_grid_launch(const float* y, const float* h_hat, const float* err_var, int no_mode,
+                      float no_scalar, const float* no_dev, const int* data_sym, const int* eff_sc,
+                      float* x_hat, float* no_eff, int B, int Nr, int Ns, int n_sym, int fft, int n_sc,
+                      int n_ds, hipStream_t stream);
+
 int ls_nn_launch(const float* y, const int* src, const float* pinv, const float* pabs2inv, float no,
                  float* h_hat, float* err_var, long planes, int plane, int T, hipStream_t stream);
 int nmse_sums_launch(const float* pred, const float* truth, double* sums, long B, int P, int C,

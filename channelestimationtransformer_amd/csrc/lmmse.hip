@@ -266,6 +266,67 @@ __global__ __launch_bounds__(256) void lmmse_direct(const float* __restrict__ y,
 }
 
 // ---------------------------------------------------------------------------------------
+// Resource-grid kernel: the operands in the layouts the equalizer OBJECT of the reference
+// receives and returns (LocalSimulations/EndtoEndtest.py:191), so that no gather / permute pass
+// runs in front of or behind the equalizer:
+//   y       [B][NR][n_sym][fft]            complex   (all OFDM symbols, all subcarriers)
+//   h_hat   [B][NR][NS][n_sym][n_sc]       complex   (effective subcarriers only)
+//   err_var null, or [B][NR][NS][n_sym][n_sc] float  (variance of the estimation error)
+//   x_hat   [B][NS][n_ds * n_sc] complex, no_eff the same in float
+// One data resource element per thread; consecutive threads take consecutive subcarriers, so
+// every load and store of a wave is one contiguous run. The noise covariance of receive antenna
+// r is no + sum over streams of err_var (diagonal); NOISE: 0 scalar `no`, 1 no_dev[B],
+// 2 no_dev[B][NR]. Without err_var and with one noise value per RE the unweighted form is used
+// (the arithmetic of lmmse_direct, antenna by antenna).
+template <int NR, int NS, int NOISE, bool ERRVAR>
+__global__ __launch_bounds__(256) void lmmse_grid(const float2* __restrict__ y,
+                                                  const float2* __restrict__ h_hat,
+                                                  const float* __restrict__ err_var, float no_scalar,
+                                                  const float* __restrict__ no_dev,
+                                                  const int* __restrict__ data_sym,
+                                                  const int* __restrict__ eff_sc,
+                                                  float2* __restrict__ x_hat,
+                                                  float* __restrict__ no_eff, int B, int n_sym, int fft,
+                                                  int n_sc, int n_ds) {
+  const int per_b = n_ds * n_sc;
+  const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (long)B * per_b) return;
+  const int b = (int)(n / per_b);
+  const int d = (int)(n - (long)b * per_b);
+  const int sd = d / n_sc, sc = d - sd * n_sc;
+  const int sym = data_sym[sd], f = eff_sc[sc];
+  constexpr bool WEIGHTED = ERRVAR || NOISE == 2;
+  Gram<NS> g;
+  g.clear();
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const size_t plane = (size_t)b * NR + r;
+    const float2 yv = y[(plane * n_sym + sym) * fft + f];
+    float hr[NS], hi[NS];
+    const float no_r = NOISE == 0 ? no_scalar : (NOISE == 1 ? no_dev[b] : no_dev[(size_t)b * NR + r]);
+    float ev = 0.f;  // summed over the streams first, then added to the noise variance
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const size_t at = ((plane * NS + k) * n_sym + sym) * n_sc + sc;
+      const float2 v = h_hat[at];
+      hr[k] = v.x;
+      hi[k] = v.y;
+      if (ERRVAR) ev += err_var[at];
+    }
+    gram_row<NS, WEIGHTED>(g, hr, hi, yv.x, yv.y, WEIGHTED ? 1.0f / (no_r + ev) : 1.0f);
+  }
+  const float lam = WEIGHTED ? 1.0f : (NOISE == 0 ? no_scalar : no_dev[b]);
+  float xr[NS], xi[NS], ne[NS];
+  lmmse_solve<NS>(g, lam, xr, xi, ne);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const size_t at = ((size_t)b * NS + k) * per_b + d;
+    x_hat[at] = make_float2(xr[k], xi[k]);
+    no_eff[at] = ne[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Tiled, LDS-DMA fed kernel (noise modes: scalar, per RE).
 
 // LDS-DMA: each lane supplies its own 16-byte (or 4-byte) global source; the wave's data lands
@@ -953,6 +1014,48 @@ int dispatch(const float* y, const float* H, int no_mode, float no_scalar, const
 }
 
 }  // namespace
+
+template <int NR, int NS>
+static int grid_dispatch(const float* y, const float* h_hat, const float* err_var, int no_mode,
+                         float no_scalar, const float* no_dev, const int* data_sym, const int* eff_sc,
+                         float* x_hat, float* no_eff, int B, int n_sym, int fft, int n_sc, int n_ds,
+                         hipStream_t stream) {
+  const long n = (long)B * n_ds * n_sc;
+  const dim3 block(256), grid((unsigned)((n + 255) / 256));
+#define CET_GRID(NOISE, EV)                                                                      \
+  hipLaunchKernelGGL((lmmse_grid<NR, NS, NOISE, EV>), grid, block, 0, stream,                     \
+                     reinterpret_cast<const float2*>(y), reinterpret_cast<const float2*>(h_hat),  \
+                     err_var, no_scalar, no_dev, data_sym, eff_sc,                                \
+                     reinterpret_cast<float2*>(x_hat), no_eff, B, n_sym, fft, n_sc, n_ds)
+  if (err_var) {
+    if (no_mode == 0) CET_GRID(0, true);
+    else if (no_mode == 1) CET_GRID(1, true);
+    else CET_GRID(2, true);
+  } else {
+    if (no_mode == 0) CET_GRID(0, false);
+    else if (no_mode == 1) CET_GRID(1, false);
+    else CET_GRID(2, false);
+  }
+#undef CET_GRID
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+
+int lmmse_grid_launch(const float* y, const float* h_hat, const float* err_var, int no_mode,
+                      float no_scalar, const float* no_dev, const int* data_sym, const int* eff_sc,
+                      float* x_hat, float* no_eff, int B, int Nr, int Ns, int n_sym, int fft, int n_sc,
+                      int n_ds, hipStream_t stream) {
+#define CET_CASE(NR, NS)         \
+  if (Nr == NR && Ns == NS)      \
+    return grid_dispatch<NR, NS>(y, h_hat, err_var, no_mode, no_scalar, no_dev, data_sym, eff_sc, \
+                                 x_hat, no_eff, B, n_sym, fft, n_sc, n_ds, stream);
+  CET_CASE(16, 4) CET_CASE(16, 2) CET_CASE(16, 1)
+  CET_CASE(8, 4) CET_CASE(8, 2) CET_CASE(8, 1)
+  CET_CASE(4, 4) CET_CASE(4, 2) CET_CASE(4, 1)
+  CET_CASE(2, 2) CET_CASE(2, 1)
+#undef CET_CASE
+  return CET_ERR_UNSUPPORTED;
+}
 
 int lmmse_launch(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
                  float* x_hat, float* no_eff, long N, int Nr, int Ns, int hshare, int variant,

@@ -145,41 +145,53 @@ class LMMSEEqualizer:
 
     def __init__(self, resource_grid, stream_management, whiten_interference=True):
         self.rg, self.sm = resource_grid, stream_management
+        self._dev_tables = {}
 
     def __call__(self, inputs):
         y, h_hat, err_var, no = inputs
         rg = self.rg
-        if y.dim() != 5 or h_hat.dim() != 7 or y.shape[1] != 1:
+        if y.dim() != 5 or h_hat.dim() != 7 or y.shape[1] != 1 or h_hat.shape[1] != 1:
             raise RuntimeError("expected y [b,1,ant,sym,fft] and h_hat [b,1,ant,tx,streams,sym,sc]")
-        b, _, ant, nsym, _ = y.shape
-        ntx, nst = h_hat.shape[3], h_hat.shape[4]
+        if not (torch.is_complex(y) and torch.is_complex(h_hat)):
+            raise RuntimeError("y and h_hat must be complex tensors")
+        b, _, ant, nsym, fft = y.shape
+        ntx, nst, n_sc = h_hat.shape[3], h_hat.shape[4], h_hat.shape[6]
+        K = ntx * nst
         dev = y.device
-        sc = torch.as_tensor(rg.effective_subcarrier_ind, device=dev)
-        sym = torch.as_tensor(rg.data_symbol_ind, device=dev)
-        # [b, ant, sym_d, sc] -> [b, sym_d, sc, ant]
-        yd = y[:, 0].index_select(3, sc).index_select(2, sym).permute(0, 2, 3, 1)
-        # [b, ant, tx, st, sym_d, sc] -> [b, sym_d, sc, ant, tx*st]
-        hd = h_hat[:, 0].index_select(4, sym).permute(0, 4, 5, 1, 2, 3)
-        hd = hd.reshape(b, len(sym), len(sc), ant, ntx * nst)
-        N = b * len(sym) * len(sc)
+        sym, sc = self._tables(dev)
+        if n_sc != sc.numel() or h_hat.shape[5] != nsym or h_hat.shape[2] != ant:
+            raise RuntimeError(f"h_hat {tuple(h_hat.shape)} does not match the resource grid")
+        # the kernel reads both tensors where they are: [b, ant, sym, fft] and [b, ant, K, sym, sc]
+        yv = torch.view_as_real(y.to(torch.complex64).contiguous()[:, 0])
+        hv = torch.view_as_real(h_hat.to(torch.complex64).contiguous()[:, 0].reshape(b, ant, K, nsym, n_sc))
         no_t = torch.as_tensor(no, dtype=torch.float32, device=dev)
         ev = torch.as_tensor(err_var, dtype=torch.float32, device=dev)
-        if ev.dim() == 0 and float(ev) == 0.0 and no_t.dim() == 0:
-            noise = float(no_t)
+        extra = 0.0
+        if ev.dim() == 0:
+            extra = K * float(ev)  # the same variance on every stream's estimate
+            ev = torch.empty(0, dtype=torch.float32, device=dev)
         else:
-            # S = no*I + diag(sum over streams of the estimation-error variance)
-            if ev.dim() > 0:
-                ev = torch.broadcast_to(ev, h_hat.shape)[:, 0].index_select(4, sym)
-                ev = ev.permute(0, 4, 5, 1, 2, 3).reshape(b, len(sym), len(sc), ant, ntx * nst).sum(-1)
-            else:
-                ev = ev * (ntx * nst)  # the same variance on every stream's estimate
-            nb = no_t.reshape(b, 1, 1, -1) if no_t.dim() > 0 else no_t
-            noise = torch.broadcast_to(ev + nb, (b, len(sym), len(sc), ant)).reshape(N, ant).contiguous()
-        x, ne = lmmse(yd.reshape(N, ant), hd.reshape(N, ant, ntx * nst), noise)
-        # [b, sym_d, sc, tx, st] -> [b, tx, st, sym_d*sc]
-        x = x.reshape(b, len(sym) * len(sc), ntx, nst).permute(0, 2, 3, 1).contiguous()
-        ne = ne.reshape(b, len(sym) * len(sc), ntx, nst).permute(0, 2, 3, 1).contiguous()
-        return x, ne
+            ev = torch.broadcast_to(ev, h_hat.shape)[:, 0].reshape(b, ant, K, nsym, n_sc).contiguous()
+        if no_t.dim() == 0:
+            mode, no_s, no_d = 0, float(no_t) + extra, torch.empty(0, dtype=torch.float32, device=dev)
+        elif no_t.numel() == b:
+            mode, no_s, no_d = 1, 0.0, (no_t.reshape(b) + extra).contiguous()
+        elif no_t.numel() == b * ant:
+            mode, no_s, no_d = 2, 0.0, (no_t.reshape(b, ant) + extra).contiguous()
+        else:
+            raise RuntimeError(f"`no` must be a scalar, [batch] or [batch, 1, ant]; got {tuple(no_t.shape)}")
+        x, ne = torch.ops.cet.lmmse_grid(yv, hv, ev, no_d, no_s, mode, sym, sc)
+        n_data = x.shape[2]
+        return (torch.view_as_complex(x).reshape(b, ntx, nst, n_data), ne.reshape(b, ntx, nst, n_data))
+
+    def _tables(self, dev):
+        """Device copies of the data-symbol and effective-subcarrier index tables (int32)."""
+        t = self._dev_tables.get(dev)
+        if t is None:
+            t = (torch.as_tensor(np.asarray(self.rg.data_symbol_ind), dtype=torch.int32, device=dev),
+                 torch.as_tensor(np.asarray(self.rg.effective_subcarrier_ind), dtype=torch.int32, device=dev))
+            self._dev_tables[dev] = t
+        return t
 
 
 class LSChannelEstimator:

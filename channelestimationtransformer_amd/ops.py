@@ -203,3 +203,39 @@ def ls_nn(y: torch.Tensor, src: torch.Tensor, pinv: torch.Tensor, pabs2inv: torc
 @ls_nn.register_fake
 def _(y, src, pinv, pabs2inv, no):
     return y.new_empty((y.shape[0], src.numel(), 2)), y.new_empty((y.shape[0], src.numel()))
+
+
+@torch.library.custom_op("cet::lmmse_grid", mutates_args=())
+def lmmse_grid(y: torch.Tensor, h_hat: torch.Tensor, err_var: torch.Tensor, no: torch.Tensor,
+               no_scalar: float, no_mode: int, data_sym: torch.Tensor,
+               eff_sc: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """y [B,Nr,n_sym,fft,2], h_hat [B,Nr,Ns,n_sym,n_sc,2] float32 (interleaved complex), err_var
+    empty or [B,Nr,Ns,n_sym,n_sc]; index tables int32 -> x_hat [B,Ns,n_ds*n_sc,2], no_eff
+    [B,Ns,n_ds*n_sc]."""
+    dev = _dev_check(y, h_hat, data_sym, eff_sc)
+    y = y.contiguous()
+    h_hat = h_hat.contiguous()
+    B, Nr, n_sym, fft = y.shape[:4]
+    Ns, n_sc = h_hat.shape[2], h_hat.shape[4]
+    n_ds = data_sym.numel()
+    if tuple(h_hat.shape[:5]) != (B, Nr, Ns, n_sym, n_sc) or eff_sc.numel() != n_sc:
+        raise RuntimeError(f"inconsistent shapes: y {tuple(y.shape)}, h_hat {tuple(h_hat.shape)}")
+    ev = err_var.contiguous() if err_var.numel() else None
+    if ev is not None and tuple(ev.shape) != (B, Nr, Ns, n_sym, n_sc):
+        raise RuntimeError(f"err_var must match h_hat, got {tuple(ev.shape)}")
+    x_hat = torch.empty((B, Ns, n_ds * n_sc, 2), dtype=torch.float32, device=dev)
+    no_eff = torch.empty((B, Ns, n_ds * n_sc), dtype=torch.float32, device=dev)
+    no_dev = no.contiguous() if no_mode != 0 else None
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().cet_lmmse_grid(_ptr(y), _ptr(h_hat), _ptr(ev), no_mode, ctypes.c_float(no_scalar),
+                                        _ptr(no_dev), _ptr(data_sym), _ptr(eff_sc), _ptr(x_hat),
+                                        _ptr(no_eff), B, Nr, Ns, n_sym, fft, n_sc, n_ds,
+                                        _cabi.current_stream_ptr(dev))
+    _cabi.check(rc, "cet_lmmse_grid")
+    return x_hat, no_eff
+
+
+@lmmse_grid.register_fake
+def _(y, h_hat, err_var, no, no_scalar, no_mode, data_sym, eff_sc):
+    B, Ns, n = y.shape[0], h_hat.shape[2], data_sym.numel() * h_hat.shape[4]
+    return y.new_empty((B, Ns, n, 2)), y.new_empty((B, Ns, n))

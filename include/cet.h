@@ -184,6 +184,23 @@ int cet_lmmse_block_llr(const float* y, const float* H, int no_mode, float no_sc
                         const float* no_dev, float* llr, long N, int h_share, int Nr, int Ns,
                         void* stream);
 
+/* The equalizer on the operands of the reference's equalizer OBJECT, in their own layouts
+ * (`lmmse_equ([y, h_hat, err_var, no])`, LocalSimulations/EndtoEndtest.py:133,191), with no
+ * gather or permute pass around it:
+ *   y        [B, Nr, n_sym, fft]          complex64 (num_rx = 1 squeezed out)
+ *   h_hat    [B, Nr, Ns, n_sym, n_sc]     complex64 (Ns = num_tx * num_streams_per_tx)
+ *   err_var  NULL, or [B, Nr, Ns, n_sym, n_sc] float32: variance of the estimation error; the
+ *            noise covariance of receive antenna r is no + sum over the streams of err_var
+ *   no_mode  0: no_scalar; 1: no_dev[B]; 2: no_dev[B, Nr]
+ *   data_sym [n_ds] int32 OFDM symbols that carry data, eff_sc [n_sc] int32 subcarrier index in
+ *            the fft grid of every effective subcarrier (device arrays)
+ *   x_hat    [B, Ns, n_ds * n_sc] complex64, no_eff the same in float32 (OFDM symbol first, then
+ *            subcarrier: pilot symbols, guard and DC carriers removed). */
+int cet_lmmse_grid(const float* y, const float* h_hat, const float* err_var, int no_mode,
+                   float no_scalar, const float* no_dev, const int32_t* data_sym,
+                   const int32_t* eff_sc, float* x_hat, float* no_eff, int B, int Nr, int Ns,
+                   int n_sym, int fft, int n_sc, int n_ds, void* stream);
+
 /* ---- LS channel estimate with nearest-neighbour interpolation ------------------------------ */
 
 /* Per-stream least-squares estimate at the pilots, spread over the resource grid by nearest

@@ -203,3 +203,49 @@ def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, kernel, oracle
     assert torch.equal(cet.lmmse_llr(yt, Ht, 0.1), cet.lmmse_llr(yt, Hbt, 0.1, h_share=h_share))
     with pytest.raises(RuntimeError):
         cet.lmmse(yt, Hbt[:-1] if nb > 1 else Ht[:0], 0.1, h_share=h_share)
+
+
+@pytest.mark.parametrize("ant,ntx,nst", [(4, 1, 2), (16, 2, 2), (8, 1, 1), (2, 1, 2)])
+def test_equalizer_object_reads_the_grid_in_place(ant, ntx, nst, oracle):
+    """The equalizer object hands y [b,1,ant,sym,fft] and h_hat [b,1,ant,tx,st,sym,sc] to one
+    kernel that gathers data symbols / effective subcarriers itself. Its arithmetic is that of
+    the one-RE-per-thread kernel on the gathered operands: the results must be bit-identical to
+    that route for a scalar, per-batch and per-antenna `no` and for a full err_var tensor, and
+    agree with the float64 checker."""
+    K = ntx * nst
+    rg = cet.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=ntx,
+                          num_streams_per_tx=nst, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                          dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    equ = cet.LMMSEEqualizer(rg, cet.StreamManagement(np.ones((1, ntx), int), nst))
+    rng = np.random.default_rng(ant + K)
+    b, n_sc = 5, rg.num_effective_subcarriers
+    cplx = lambda *s: (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)
+    y, h = cplx(b, 1, ant, 14, 76), cplx(b, 1, ant, ntx, nst, 14, n_sc)
+    ev = rng.uniform(0.0, 0.2, h.shape).astype(np.float32)
+    sym, sc = np.asarray(rg.data_symbol_ind), np.asarray(rg.effective_subcarrier_ind)
+    n_d = len(sym) * n_sc
+    yd = y[:, 0][:, :, sym][:, :, :, sc].transpose(0, 2, 3, 1).reshape(-1, ant)
+    hd = h[:, 0].reshape(b, ant, K, 14, n_sc)[:, :, :, sym].transpose(0, 3, 4, 1, 2).reshape(-1, ant, K)
+    evd = ev[:, 0].reshape(b, ant, K, 14, n_sc)[:, :, :, sym].transpose(0, 3, 4, 1, 2).reshape(-1, ant, K).sum(-1)
+    yt, ht = torch.from_numpy(y).cuda(), torch.from_numpy(h).cuda()
+    no_b = rng.uniform(0.05, 0.5, b).astype(np.float32)
+    no_ba = rng.uniform(0.05, 0.5, (b, 1, ant)).astype(np.float32)
+    per_re = lambda v: np.broadcast_to(v, (b, len(sym), n_sc, ant)).reshape(-1, ant).astype(np.float32).copy()
+    cases = [
+        (0.0, 0.2, 0.2),
+        (0.0, torch.from_numpy(no_b).cuda(), np.repeat(no_b, n_d)),
+        (0.0, torch.from_numpy(no_ba).cuda(), per_re(no_ba.reshape(b, 1, 1, ant))),
+        (torch.from_numpy(ev).cuda(), 0.2, np.float32(0.2) + evd),
+        (torch.from_numpy(ev).cuda(), torch.from_numpy(no_ba).cuda(), per_re(no_ba.reshape(b, 1, 1, ant)) + evd),
+        (torch.tensor(0.03), torch.from_numpy(no_b).cuda(), np.repeat(no_b, n_d) + K * 0.03),
+    ]
+    back = lambda a: a.reshape(b, n_d, ntx, nst).transpose(0, 2, 3, 1)
+    for err_var, no, flat_no in cases:
+        x_hat, no_eff = equ([yt, ht, err_var, no])
+        assert x_hat.shape == no_eff.shape == (b, ntx, nst, n_d)
+        fn = flat_no if np.isscalar(flat_no) else torch.from_numpy(np.ascontiguousarray(flat_no, np.float32)).cuda()
+        xf, nf = cet.lmmse(torch.from_numpy(yd).cuda(), torch.from_numpy(hd).cuda(), fn, direct=True)
+        assert np.array_equal(x_hat.cpu().numpy(), back(xf.cpu().numpy()))
+        assert np.array_equal(no_eff.cpu().numpy(), back(nf.cpu().numpy()))
+        wx, wne = oracle.lmmse(yd, hd, flat_no)
+        assert close(x_hat.cpu().numpy(), back(wx)) and close(no_eff.cpu().numpy(), back(wne))
