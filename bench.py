@@ -145,6 +145,34 @@ def cpu_baseline_informer(ck, x, xd, budget_s=15.0):
                       f"(C restatement, OpenMP over sequences, {threads} threads)"}
 
 
+def cpu_baseline_torch(run, n_total, what, budget_s=10.0):
+    """Stock PyTorch on the host cores (the reference's CPU path runs the same ATen kernels):
+    `run(n)` processes the first n sequences with oracle/torch_ref.py. Timed with all the
+    threads the box grants (at most 16) for about `budget_s` seconds, and briefly with one.
+    Returns (cpu_baseline object, one-thread object)."""
+    res = []
+    for threads, budget in ((min(16, os.cpu_count() or 1), budget_s), (1, budget_s / 3)):
+        torch.set_num_threads(threads)
+        n = 64
+        run(n)  # warm-up
+        t0 = time.perf_counter()
+        run(n)
+        dt = time.perf_counter() - t0
+        n2 = int(min(n_total, max(n, n * budget / max(dt, 1e-4))))
+        t0 = time.perf_counter()
+        run(n2)  # large batches run faster per sequence than the 64 used for sizing
+        dt = time.perf_counter() - t0
+        reps = int(min(500, max(1, round(budget / max(dt, 1e-4)))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run(n2)
+        dt = time.perf_counter() - t0
+        res.append({"value": n2 * reps / dt, "unit": "predictions/s", "cores": threads, "kind": "port",
+                    "sample": f"{reps} x {n2} of the benchmark's sequences ({dt:.1f} s): {what}"})
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # also the OpenMP setting of the C checker
+    return res[0], res[1]
+
+
 def cpu_baseline_rnn(kind, sd, x, pred_len, budget_s=15.0):
     from oracle import pyoracle
     kid = blobs.RNN_KINDS[kind]
@@ -268,7 +296,17 @@ def main():
             "max_abs_delta_db": float((nm_ours - nm_ref).abs().max()),
             "max_abs_err_vs_reference_output": float((ours.cpu() - torch.from_numpy(ref_out)).abs().max())}
         if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_informer(ck, x.cpu().numpy(), xd.cpu().numpy())
+            # the baseline: stock PyTorch on the host cores (the ATen CPU kernels the reference's own
+            # CPU path runs); beside it the same with one thread and the scalar C checker
+            from oracle import torch_ref
+            xc, xdc = x.cpu(), xd.cpu()
+            with torch.no_grad():
+                out["cpu_baseline"], one = cpu_baseline_torch(
+                    lambda n: torch_ref.informer_forward(ck, xc[:n], xdc[:n], 5), B,
+                    "InformerStack forward in stock torch.nn.functional calls (oracle/torch_ref.py)")
+            out["cpu_baseline_other"] = {
+                "torch_one_thread": one,
+                "c_checker": cpu_baseline_informer(ck, x.cpu().numpy(), xd.cpu().numpy(), budget_s=5.0)}
 
         if rank == 0 and n_gpus == 1 and not args.skip_secondary:
             # secondary lines: the other kernels of the path, shorter runs
@@ -502,7 +540,14 @@ def main():
                          "kernel": "rnn_rollout_kernel", "kernel_ms": dev_s * 1e3, "flop_per_launch": flop},
         })
         if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_rnn(kind, sd, x.cpu().numpy(), P)
+            from oracle import torch_ref
+            xc = x.cpu()
+            out["cpu_baseline"], one = cpu_baseline_torch(
+                lambda n: torch_ref.rnn_rollout(sd, kind, xc[:n], P), B,
+                f"stock torch.nn.{kind.upper()} rollout (oracle/torch_ref.py)")
+            out["cpu_baseline_other"] = {
+                "torch_one_thread": one,
+                "c_checker": cpu_baseline_rnn(kind, sd, x.cpu().numpy(), P, budget_s=5.0)}
 
     if extra:
         out["secondary"] = extra
