@@ -2,8 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY, like oracle/cet_oracle.c: used by tests/ as a checker that shares no
 code with the C restatement or the HIP kernels, and by bench.py as the "stock PyTorch on the host
-cores" baseline. It works on a reference-style state_dict (name -> tensor) and never touches
-the GPU library.
+cores" baseline. It works on a reference-style state_dict (name -> tensor or numpy array) and never touches
+the GPU library; with the state_dict and the inputs on a ROCm device it runs stock PyTorch-ROCm
+there (the full-size cross-check of tests/test_gpu_torch_ref.py).
 
 The functions follow the reference's modules:
   embedding     LocalSimulations/models/embed.py:7-53 (circular Conv1d k=3 + stored `pe`)
@@ -39,7 +40,7 @@ def _attention(sd, pre, q_in, kv_in, n_heads, causal):
     v = lin("value", kv_in).view(B, S, n_heads, -1)
     scores = torch.einsum("blhe,bshe->bhls", q, k)
     if causal:
-        scores = scores.masked_fill(torch.triu(torch.ones(L, S, dtype=torch.bool), 1), -math.inf)
+        scores = scores.masked_fill(torch.triu(torch.ones(L, S, dtype=torch.bool, device=scores.device), 1), -math.inf)
     a = torch.softmax(scores / math.sqrt(q.shape[-1]), dim=-1)
     ctx = torch.einsum("bhls,bshd->blhd", a, v).reshape(B, L, -1)
     return lin("out", ctx), a
@@ -110,8 +111,9 @@ def rnn_rollout(sd, cell, x, pred_len):
     inp = w("model.encoder.0.weight").shape[0]
     mod = {"rnn": torch.nn.RNN, "gru": torch.nn.GRU, "lstm": torch.nn.LSTM}[cell](inp, hidden, layers)
     mod.load_state_dict({k[len(f"model.{cell}."):]: w(k) for k in sd if k.startswith(f"model.{cell}.")})
+    mod = mod.to(x.device)
     B, seq_len, _ = x.shape
-    state = torch.zeros(layers, B, hidden)
+    state = torch.zeros(layers, B, hidden, device=x.device)
     if cell == "lstm":
         state = (state, state.clone())
     outs, out = [], None
