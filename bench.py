@@ -317,6 +317,19 @@ def main():
             extra[f"informer_output_attention_{not want_maps}"] = {
                 "predictions_per_s": B / d2, "kernel_ms": d2 * 1e3,
                 "mfma_frac": INFORMER_FLOP * B / d2 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+            # the reference's own GPU path on this card: the model in stock PyTorch-ROCm eager
+            # calls (oracle/torch_ref.py on device tensors), same weights, same batch
+            from oracle import torch_ref as _tr
+            sd_dev = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in ck.items()}
+            def step_eager():
+                with torch.no_grad():
+                    _tr.informer_forward(sd_dev, x, xd, 5)
+            _w, de = timed_loop(step_eager, 10, 3, False, dev)
+            extra["stock_pytorch_rocm_eager_same_gpu"] = {
+                "predictions_per_s": B / de, "step_ms": de * 1e3,
+                "speedup_of_the_hip_kernel": de / dev_s,
+                "note": "InformerStack forward, B=4096, torch.nn.functional calls on the MI355X (about 190 kernel launches)"}
+            del sd_dev
             # the same step fed from and returning to pinned host memory (Predict.py:99-117
             # moves every batch numpy -> GPU -> numpy); never the headline value
             xh, xdh = x.cpu().pin_memory(), xd.cpu().pin_memory()
@@ -402,9 +415,14 @@ def main():
                     rm.test_data(xr, 5, dev)
                 w4, d4 = timed_loop(step4, 10, 2, False, dev)
                 fl = RNN_FLOP_PER_STEP[kind] * 29 * 8192
+                sd_dev = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in _sd.items()}
+                def step4e():
+                    _tr.rnn_rollout(sd_dev, kind, xr, 5)
+                _w, d4e = timed_loop(step4e, 5, 2, False, dev)
                 extra[f"{kind}_rollout_B8192_pred5"] = {
                     "predictions_per_s": 8192 / d4, "kernel_ms": d4 * 1e3,
-                    "mfma_frac": fl / d4 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+                    "mfma_frac": fl / d4 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "stock_pytorch_rocm_eager_ms": d4e * 1e3, "speedup_of_the_hip_kernel": d4e / d4}
 
     elif args.workload == "e2e":
         # Transformer prediction of 5 future slots per subcarrier sample -> LMMSE over the 14
