@@ -1,20 +1,27 @@
 """Throughput benchmark of the predictor + LMMSE inference path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-                    [--workload informer|lmmse|lstm|gru|rnn|e2e] [--batch B] [--pred-len P]
-                    [--h-share n] [--geometry reference|scaled] [--no-attention-maps]
+                    [--workload informer|lmmse|lstm|gru|rnn|e2e|selftest] [--batch B]
+                    [--pred-len P] [--h-share n] [--geometry reference|scaled]
+                    [--no-attention-maps]
 
 One "step" is one pass of the hot path over one batch of synthetic input that is already
 resident in HBM. The default workload is the Transformer predictor forward on 4096 channel
 sequences per GPU (InformerStack, the constructor arguments of LocalSimulations/Predict.py:
-21-38, shipped checkpoint weights). With N > 1 (one process per GPU, launched by
-torch.distributed.run) every rank runs the same per-GPU batch (weak scaling); the only
-collective is one RCCL all-reduce of the NMSE partial sums at the end of the timed region.
-Rank 0 prints ONE JSON line.
+21-38, shipped checkpoint weights). With N > 1 every rank (one process per GPU) runs the same
+per-GPU batch (weak scaling); the only collective is one RCCL all-reduce of the NMSE partial sums
+at the end of the timed region. Under torch.distributed.run (WORLD_SIZE set) the process is one
+rank of N; started without a launcher, `--gpus N` makes it start the N ranks itself, as a child
+process tree and before it touches a GPU, and exit with their status (this replaces the
+reference's torch.nn.DataParallel wrapper, HPC/python/Evaluate.py:74). Rank 0 prints ONE JSON
+line. `--workload selftest` runs the launcher, the rendezvous and the all-reduce on the CPU with
+the gloo backend (no GPU work; used by the CPU tests).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -52,12 +59,12 @@ def measured_traffic(workload, units, per_unit_key=None):
     return best
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="informer", choices=["informer", "lmmse", "lstm", "gru", "rnn", "e2e"])
+    ap.add_argument("--workload", default="informer", choices=["informer", "lmmse", "lstm", "gru", "rnn", "e2e", "selftest"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (sequences or REs)")
     ap.add_argument("--pred-len", type=int, default=25, help="rollout horizon of the recurrent workloads")
     ap.add_argument("--no-attention-maps", action="store_true",
@@ -69,7 +76,7 @@ def parse():
                          "sequences per subcarrier)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-secondary", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def torch_sd(npz_dict):
@@ -225,22 +232,412 @@ def lmmse_inputs(N, Nr, Ns, no, dev, seed, h_share=1):
     return y.contiguous(), Hc, xs
 
 
-def main():
-    args = parse()
+class Ctx:
+    """Where this rank runs: device, rank numbering, whether a process group exists."""
+
+    def __init__(self, dev, rank, n_gpus, dist_on):
+        self.dev, self.rank, self.n_gpus, self.dist_on = dev, rank, n_gpus, dist_on
+
+    def max_over_ranks(self, seconds):
+        if not self.dist_on:
+            return seconds
+        import torch.distributed as dist
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+
+def free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Starts `n` ranks of this script on this node through torch.distributed.run, as a child
+    process (this process has not touched a GPU: no HIP call and no torch.cuda call other than
+    device_count precedes this), waits for them and returns their exit status. Rank 0 of the
+    children prints the JSON line on the shared stdout."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC, which RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rnn_nmse_check(kind, dev):
+    """NMSE of this path's rollout and of the reference's own outputs (captured from the imported
+    reference, tests/golden/rnn_cr.npz) on the reference's stored CDL-B sequences, against the same
+    truth (slots 25..29 of CR_data_*), with the reference's checkpoint that was trained on that
+    data set (prediciton_code/checkpoints/checkpoints_30-60_L5): the accuracy contract of the
+    recurrent predictors."""
+    g = np.load(os.path.join(GOLDEN, "rnn_cr.npz"))
+    name = f"{kind.upper()}_L5"
+    sd = {k[len(name) + 4:]: g[k] for k in g.files if k.startswith(name + "/sd/")}
+    model = getattr(cet, kind.upper())(16, 16, 256, 2)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    model.eval()
+    x = torch.from_numpy(g["x"]).to(dev)
+    truth = torch.from_numpy(g["truth"]).to(dev)
+    ref = torch.from_numpy(g[f"{name}/pred5"]).to(dev)
+    ours = model.test_data(x, 5, dev)
+    nm_ours = metrics.nmse_db(metrics.nmse_partial_sums(ours, truth)).cpu()
+    nm_ref = metrics.nmse_db(metrics.nmse_partial_sums(ref, truth)).cpu()
+    return {"data": f"CR_data_30/36/60 ({x.shape[0]} CDL-B sequences shipped with the reference), "
+                    f"checkpoint checkpoints_30-60_L5/{kind.upper()}_data_0_sl25_pl5_hs256_hl2",
+            "nmse_db_per_slot": [round(float(v), 4) for v in nm_ours],
+            "reference_nmse_db_per_slot": [round(float(v), 4) for v in nm_ref],
+            "max_abs_delta_db": float((nm_ours - nm_ref).abs().max()),
+            "max_abs_err_vs_reference_output": float((ours - ref).abs().max())}
+
+
+def run_rnn(ctx, kind, B, P, steps, warmup, cpu_baseline=False):
+    """Recurrent rollout (`test_data`, seq_len 25, pred_len P) on B sequences per GPU."""
+    dev = ctx.dev
+    model, sd = make_rnn(kind)
+    noisy, _ = synth.channel_histories(B, T=25 + 5, seed=ctx.rank)
+    x = cet.LoadBatch(noisy[:, :25]).to(dev)
+    holder = {}
+
+    def step():
+        holder["pred"] = model.test_data(x, P, dev)
+
+    wall, dev_s = timed_loop(step, steps, warmup, ctx.dist_on, dev)
+    wall = ctx.max_over_ranks(wall)
+    flop = RNN_FLOP_PER_STEP[kind] * (24 + P) * B
+    achieved = flop / dev_s / 1e12
+    out = {
+        "metric": f"channel predictions/s ({kind.upper()} rollout)",
+        "value": B * ctx.n_gpus * steps / wall, "unit": "predictions/s",
+        "ms_per_step": wall / steps * 1e3, "dtype": "f32",
+        "config": {"workload": f"{kind.upper()}(16,16,256,2).test_data, seq_len 25, pred_len {P}, shipped checkpoint",
+                   "batch_per_gpu": B, "global_batch": B * ctx.n_gpus, "parallelism": f"dp{ctx.n_gpus}"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "rnn_rollout_kernel", "kernel_ms": dev_s * 1e3, "flop_per_launch": flop},
+    }
+    out["nmse_check"] = rnn_nmse_check(kind, dev)
+    if cpu_baseline:
+        from oracle import torch_ref
+        xc = x.cpu()
+        out["cpu_baseline"], one = cpu_baseline_torch(
+            lambda n: torch_ref.rnn_rollout(sd, kind, xc[:n], P), B,
+            f"stock torch.nn.{kind.upper()} rollout (oracle/torch_ref.py)")
+        out["cpu_baseline_other"] = {
+            "torch_one_thread": one,
+            "c_checker": cpu_baseline_rnn(kind, sd, x.cpu().numpy(), P, budget_s=5.0)}
+    return out
+
+
+def run_lmmse(ctx, N, hs, steps, warmup, cpu_baseline=False):
+    """LMMSE 16x4 on N resource elements per GPU (hs > 1: one channel matrix per hs elements)."""
+    dev = ctx.dev
+    Nr, Ns, no = 16, 4, 0.1
+    y, H, xs = lmmse_inputs(N, Nr, Ns, no, dev, ctx.rank, hs)
+    holder = {}
+
+    def step():
+        holder["x"], holder["ne"] = cet.lmmse(y, H, no, h_share=hs)
+
+    wall, dev_s = timed_loop(step, steps, warmup, ctx.dist_on, dev)
+    bits = metrics.qpsk_bit_errors(holder["x"], xs)
+    metrics.all_reduce_sums(bits)
+    wall = ctx.max_over_ranks(wall)
+    bytes_re = LMMSE_BYTES[(Nr, Ns)] - Nr * Ns * 8 * (1.0 - 1.0 / hs)  # H once per block
+    gbs = bytes_re * N / dev_s / 1e9
+    out = {
+        "metric": "LMMSE-equalized REs/s", "value": N * ctx.n_gpus * steps / wall, "unit": "REs/s",
+        "ms_per_step": wall / steps * 1e3, "dtype": "complex64 (f32 arithmetic)",
+        "config": {"workload": f"LMMSE {Nr}x{Ns}, {N} REs per GPU, no=0.1"
+                               + (" (3276 subcarriers x 14 symbols x 1024 slots)" if N == 3276 * 14 * 1024 else "")
+                               + (f", block fading: one H per {hs} REs, {bytes_re:.1f} B/RE" if hs > 1 else ""),
+                   "parallelism": f"dp{ctx.n_gpus}"},
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": gbs / PEAK_HBM_GBS,
+                     "traffic": measured_traffic("lmmse", N) if hs == 1 else None,
+                     "kernel": "lmmse_tiled<16,4,2>" if hs == 1 else "lmmse_block<16,4,2>",
+                     "kernel_ms": dev_s * 1e3, "bytes_per_launch": bytes_re * N},
+        "ber": float(bits[0] / bits[1]),
+    }
+    if cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_lmmse(Nr, Ns, no)
+    return out
+
+
+def run_e2e(ctx, scaled, S, steps, warmup):
+    """Transformer prediction of 5 future slots per subcarrier sample -> LMMSE over the 14 OFDM
+    symbols of each predicted slot -> hard-decision QPSK bit errors and per-slot NMSE; ranks hold
+    disjoint subcarrier ranges. S = predictor sequences (4x2 antenna groups) per GPU."""
+    dev, rank = ctx.dev, ctx.rank
+    n_sym, no = 14, 0.05
+    Nr, Nt = (16, 4) if scaled else (4, 2)
+    model, ck = make_informer(False)
+    # the checkpoint predicts CDL-B channels: the reference's 192 stored sequences, tiled
+    cr = np.load(os.path.join(GOLDEN, "cr_pairs.npz"))
+    real = np.concatenate([cr["data_30"], cr["data_36"], cr["data_60"]])
+    real = np.roll(real, 7 * rank, axis=0)[np.arange(S) % real.shape[0]]
+    real = torch.from_numpy(real).to(dev).to(torch.complex64)
+    if scaled:  # eight stored 4x2 sequences make one 16x4 subcarrier sample
+        real = e2e.ungroup_antennas(real[:S - S % 8], Nr, Nt)
+    h_hist, h_future = real[:, :25].contiguous(), real[:, 25:30].contiguous()
+    n_sc = h_hist.shape[0]
+    g = torch.Generator(device=dev).manual_seed(rank)
+    y, xs = e2e.transmit(h_future, n_sym, no, g)
+    holder = {}
+    predict = e2e.predict_slots_grouped if scaled else e2e.predict_slots
+
+    def step():
+        h_hat = predict(model, h_hist, 10, 5)
+        x_hat, _ = e2e.equalize_slots(h_hat, y, no)
+        bits = metrics.qpsk_bit_errors(x_hat, xs)
+        holder["sums"] = {"nmse": metrics.nmse_partial_sums(h_hat, h_future), "bits": bits,
+                          "bits_perfect": bits}  # replaced after the timed region
+
+    wall, dev_s = timed_loop(step, steps, warmup, ctx.dist_on, dev)
+    # outside the timed region: the same link equalized with the true channel, and with the
+    # prediction error's variance passed to the equalizer
+    x_true, _ = e2e.equalize_slots(h_future.to(torch.complex64), y, no)
+    holder["sums"]["bits_perfect"] = metrics.qpsk_bit_errors(x_true, xs)
+    h_hat = predict(model, h_hist, 10, 5)
+    err_var = float((h_hat - h_future).abs().pow(2).mean())
+    x_ev, _ = e2e.equalize_slots(h_hat, y, no, err_var)
+    bits_ev = metrics.qpsk_bit_errors(x_ev, xs)
+    metrics.all_reduce_sums(bits_ev)
+    res = e2e.reduce(holder["sums"])  # the path's only collective (RCCL)
+    wall = ctx.max_over_ranks(wall)
+    n_re = n_sc * 5 * n_sym
+    frac = INFORMER_FLOP * S / dev_s / 1e12 / PEAK_FP32_MFMA_TFLOPS
+    return {
+        "metric": "channel predictions/s (Transformer prediction + LMMSE equalization + BER/NMSE)",
+        "value": S * ctx.n_gpus * steps / wall, "unit": "predictions/s",
+        "ms_per_step": wall / steps * 1e3, "dtype": "f32",
+        "data": "the reference's stored CDL-B sequences (CR_data_30/36/60), tiled; synthetic QPSK + AWGN",
+        "config": {"workload": f"end to end: InformerStack default configuration on {S} 4x2 antenna "
+                               f"groups = {n_sc} subcarrier samples per GPU ({Nr}x{Nt} channel), "
+                               f"block-fading LMMSE {Nr}x{Nt} on {n_re} REs "
+                               f"(5 slots x {n_sym} symbols), QPSK, no={no}",
+                   "parallelism": f"dp{ctx.n_gpus} (subcarrier ranges)"},
+        "roofline": {"bound": "mfma", "achieved": frac * PEAK_FP32_MFMA_TFLOPS,
+                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": frac, "traffic": None,
+                     "kernel": "whole step (informer_kernel + lmmse + reductions + torch glue)",
+                     "kernel_ms": dev_s * 1e3},
+        "equalized_REs_per_s": n_re * ctx.n_gpus * steps / wall,
+        "ber": res["ber"], "ber_perfect_csi": res["ber_perfect_csi"],
+        "ber_with_err_var": float(bits_ev[0] / bits_ev[1]), "err_var": err_var,
+        "nmse_db_per_slot": [round(v, 3) for v in res["nmse_db"]],
+    }
+
+
+def run_selftest(ctx):
+    """No GPU work: every rank forms the NMSE partial sums of its contiguous shard of a seeded
+    batch on the CPU, one all-reduce sums them, rank 0 checks the total against the whole batch.
+    Exercises the launcher, the rendezvous and the collective exactly as the GPU workloads use
+    them (backend gloo instead of RCCL)."""
+    per_rank = 8
+    B = per_rank * ctx.n_gpus
+    g = torch.Generator().manual_seed(0)
+    truth = torch.randn(B, 5, 16, generator=g)
+    pred = truth + 0.1 * torch.randn(B, 5, 16, generator=g)
+    lo = ctx.rank * per_rank
+    t0 = time.perf_counter()
+    sums = metrics.nmse_partial_sums(pred[lo:lo + per_rank], truth[lo:lo + per_rank])
+    metrics.all_reduce_sums(sums)
+    wall = ctx.max_over_ranks(time.perf_counter() - t0)
+    want = metrics.nmse_partial_sums(pred, truth)
+    ok = bool(torch.allclose(sums, want, rtol=1e-12))
+    return {"metric": "launcher self-test (CPU, gloo)", "value": B / max(wall, 1e-9), "unit": "sequences/s",
+            "ms_per_step": wall * 1e3, "dtype": "f64", "config": {"workload": "selftest", "global_batch": B},
+            "all_reduce_matches_single_process": ok,
+            "nmse_db_per_slot": [round(float(v), 6) for v in metrics.nmse_db(sums)]}
+
+
+def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
+    """The other kernels and configurations of the path, shorter runs, each with its own roofline
+    object; all inside the default run so that one driver record covers the whole metric."""
+    dev = ctx.dev
+    B = x.shape[0]
+    extra = {}
+
+    def roof(bound, achieved, kernel_ms, **more):
+        peak = PEAK_FP32_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS
+        r = {"bound": bound, "achieved": achieved, "peak": peak,
+             "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": achieved / peak, "kernel_ms": kernel_ms}
+        r.update(more)
+        return r
+
+    model2, _ = make_informer(not want_maps)
+    def step2():
+        model2(x, xd)
+    _w, d2 = timed_loop(step2, max(5, args.steps // 5), 2, False, dev)
+    extra[f"informer_output_attention_{not want_maps}"] = {
+        "predictions_per_s": B / d2, "kernel_ms": d2 * 1e3,
+        "mfma_frac": INFORMER_FLOP * B / d2 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "roofline": roof("mfma", INFORMER_FLOP * B / d2 / 1e12, d2 * 1e3)}
+    # the reference's own GPU path on this card: the model in stock PyTorch-ROCm eager
+    # calls (oracle/torch_ref.py on device tensors), same weights, same batch
+    from oracle import torch_ref as _tr
+    sd_dev = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in ck.items()}
+    def step_eager():
+        with torch.no_grad():
+            _tr.informer_forward(sd_dev, x, xd, 5)
+    _w, de = timed_loop(step_eager, 10, 3, False, dev)
+    extra["stock_pytorch_rocm_eager_same_gpu"] = {
+        "predictions_per_s": B / de, "step_ms": de * 1e3,
+        "speedup_of_the_hip_kernel": de / dev_s,
+        "note": f"InformerStack forward, B={B}, torch.nn.functional calls on the MI355X (about 190 kernel launches)"}
+    del sd_dev
+    # the same step fed from and returning to pinned host memory (Predict.py:99-117
+    # moves every batch numpy -> GPU -> numpy); never the headline value
+    xh, xdh = x.cpu().pin_memory(), xd.cpu().pin_memory()
+    oh = torch.empty(B, 5, 16).pin_memory()
+    def step_host():
+        r = model(xh.to(dev, non_blocking=True), xdh.to(dev, non_blocking=True))
+        oh.copy_(r[0] if want_maps else r, non_blocking=True)
+    _w, dh = timed_loop(step_host, max(5, args.steps // 5), 2, False, dev)
+    extra["informer_with_host_transfers"] = {
+        "predictions_per_s": B / dh, "step_ms": dh * 1e3,
+        "note": "pinned host input (x_enc, x_dec) -> device -> forward -> prediction to pinned host"}
+
+    # ---- LMMSE: the stated size of the metric's second half, then the other shapes -------------
+    one = Ctx(dev, 0, 1, False)
+    r = run_lmmse(one, 3276 * 14 * 1024, 1, 10, 2)
+    extra["lmmse_16x4_46964736_REs"] = {"REs_per_s": r["value"], "kernel_ms": r["roofline"]["kernel_ms"],
+                                        "N": 3276 * 14 * 1024, "ber": r["ber"], "roofline": r["roofline"]}
+    torch.cuda.empty_cache()
+    N = 1 << 23
+    r = run_lmmse(one, N, 1, 10, 2)
+    extra["lmmse_16x4"] = {"REs_per_s": r["value"], "kernel_ms": r["roofline"]["kernel_ms"], "N": N,
+                           "hbm_GBps": r["roofline"]["achieved"], "hbm_frac": r["roofline"]["frac"],
+                           "roofline": r["roofline"]}
+    r = run_lmmse(one, N, 14, 10, 2)
+    extra["lmmse_16x4_block_fading_14"] = {
+        "REs_per_s": r["value"], "kernel_ms": r["roofline"]["kernel_ms"], "N": N,
+        "bytes_per_RE": r["roofline"]["bytes_per_launch"] / N, "hbm_GBps": r["roofline"]["achieved"],
+        "hbm_frac": r["roofline"]["frac"], "roofline": r["roofline"]}
+    torch.cuda.empty_cache()
+    # the reference-sized equalizer shapes (4 x 2 of EndtoEndtest.py, 8 x 4)
+    for (nr, ns) in ((8, 4), (4, 2)):
+        Nv = 1 << 24
+        yv, Hv, _xs = lmmse_inputs(Nv, nr, ns, 0.1, dev, 0)
+        def step3b():
+            cet.lmmse(yv, Hv, 0.1)
+        _w, dv = timed_loop(step3b, 10, 2, False, dev)
+        bpr = LMMSE_BYTES[(nr, ns)]
+        extra[f"lmmse_{nr}x{ns}"] = {"REs_per_s": Nv / dv, "kernel_ms": dv * 1e3, "N": Nv,
+                                     "hbm_GBps": bpr * Nv / dv / 1e9,
+                                     "hbm_frac": bpr * Nv / dv / 1e9 / PEAK_HBM_GBS,
+                                     "roofline": roof("hbm", bpr * Nv / dv / 1e9, dv * 1e3)}
+        del yv, Hv
+    # the reference's receive chain on its own grid (EndtoEndtest.py:50-59, 130-133, 184-191):
+    # LS estimate with nearest-neighbour interpolation -> LMMSEEqualizer object, 4 rx x 2 streams
+    rg = cet.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=1,
+                          num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                          dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    est = cet.LSChannelEstimator(rg, interpolation_type="nn")
+    equ = cet.LMMSEEqualizer(rg, cet.StreamManagement(np.array([[1]]), 2))
+    nb = 8192
+    yg = torch.view_as_complex(torch.randn(nb, 1, 4, 14, 76, 2, device=dev))
+    hold2 = {}
+    def step_ls():
+        hold2["h"], hold2["e"] = est([yg, 0.1])
+    _w, dls = timed_loop(step_ls, 10, 2, False, dev)
+    def step_eq():
+        equ([yg, hold2["h"], hold2["e"], 0.1])
+    _w, deq = timed_loop(step_eq, 10, 2, False, dev)
+    n_out = nb * 4 * 2 * 14 * 64
+    extra["receive_chain_reference_grid"] = {
+        "batch": nb, "ls_nn_ms": dls * 1e3, "ls_nn_GBps": (n_out * 12 + yg.numel() * 8) / dls / 1e9,
+        "equalizer_object_ms": deq * 1e3, "equalizer_object_REs_per_s": nb * 12 * 64 / deq,
+        # per data RE: y 4x8 + h_hat 8x8 + err_var 8x4 + x_hat 2x8 + no_eff 2x4 bytes
+        "equalizer_object_GBps": nb * 12 * 64 * 152.0 / deq / 1e9,
+        "roofline": roof("hbm", nb * 12 * 64 * 152.0 / deq / 1e9, deq * 1e3, kernel="lmmse_grid<4,2>")}
+    del yg, hold2
+    torch.cuda.empty_cache()
+
+    # ---- the reference's own CPU-runnable case: 64 sequences (latency, not throughput) ---------
+    x64, xd64 = x[:64].contiguous(), xd[:64].contiguous()
+    def step64():
+        model(x64, xd64)
+    _w, d64 = timed_loop(step64, 20, 3, False, dev)
+    lat = {"informer_ms": d64 * 1e3, "informer_predictions_per_s": 64 / d64}
+    for kind in ("gru", "lstm", "rnn"):
+        gm, _sd = make_rnn(kind)
+        def step64g():
+            gm.test_data(x64, 5, dev)
+        _w, d64g = timed_loop(step64g, 20, 3, False, dev)
+        lat[f"{kind}_pred5_ms"] = d64g * 1e3
+        lat[f"{kind}_predictions_per_s"] = 64 / d64g
+    extra["batch_64_latency"] = lat
+
+    # ---- recurrent rollouts, 8192 sequences, pred_len 5 / 25 / 100 ------------------------------
+    for kind in ("lstm", "gru", "rnn"):
+        rm, _sd = make_rnn(kind)
+        nbh, _ = synth.channel_histories(8192, seed=1)
+        xr = cet.LoadBatch(nbh[:, :25]).to(dev)
+        sd_dev = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in _sd.items()}
+        for P in (5, 25, 100):
+            def step4():
+                rm.test_data(xr, P, dev)
+            _w, d4 = timed_loop(step4, 10 if P < 100 else 5, 2, False, dev)
+            fl = RNN_FLOP_PER_STEP[kind] * (24 + P) * 8192
+            line = {"predictions_per_s": 8192 / d4, "kernel_ms": d4 * 1e3,
+                    "mfma_frac": fl / d4 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "roofline": roof("mfma", fl / d4 / 1e12, d4 * 1e3, flop_per_launch=fl)}
+            if P == 5:
+                def step4e():
+                    _tr.rnn_rollout(sd_dev, kind, xr, 5)
+                _w, d4e = timed_loop(step4e, 5, 2, False, dev)
+                line["stock_pytorch_rocm_eager_ms"] = d4e * 1e3
+                line["speedup_of_the_hip_kernel"] = d4e / d4
+                line["nmse_check"] = rnn_nmse_check(kind, dev)
+            extra[f"{kind}_rollout_B8192_pred{P}"] = line
+        del sd_dev
+
+    # ---- end to end, both geometries --------------------------------------------------------------
+    for geometry in ("reference", "scaled"):
+        r = run_e2e(one, geometry == "scaled", 3276 * 8, 10, 2)
+        extra[f"e2e_{geometry}_geometry"] = {
+            k: r[k] for k in ("value", "unit", "ms_per_step", "equalized_REs_per_s", "ber", "ber_perfect_csi",
+                              "ber_with_err_var", "nmse_db_per_slot", "roofline")}
+        extra[f"e2e_{geometry}_geometry"]["workload"] = r["config"]["workload"]
+    return extra
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: become one (nothing here has touched a GPU yet)
+        if args.workload != "selftest" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        raise SystemExit(launch_ranks(args.gpus, argv))
+
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ  # under torchrun, also at N = 1
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if dist_on:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cpu_only = args.workload == "selftest"
+    if cpu_only:
+        dev = torch.device("cpu")
+        if dist_on:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if dist_on:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctx = Ctx(dev, rank, world, dist_on)
     n_gpus = world
 
     out = {"n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     extra = {}
+    with_cpu = rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline
 
     if args.workload == "informer":
         B = args.batch or 4096
@@ -259,10 +656,7 @@ def main():
         wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
         sums = metrics.nmse_partial_sums(holder["pred"], truth)
         metrics.all_reduce_sums(sums)  # the path's only collective (RCCL)
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        if dist_on:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t)
+        wall = ctx.max_over_ranks(wall)
         achieved = INFORMER_FLOP * B / dev_s / 1e12
         out.update({
             "metric": "channel predictions/s (Transformer predictor forward)",
@@ -277,6 +671,7 @@ def main():
                          "traffic": measured_traffic("informer" if want_maps else "informer_nomaps", B),
                          "kernel": "informer_kernel", "kernel_ms": dev_s * 1e3,
                          "flop_per_launch": INFORMER_FLOP * B},
+            "nmse_db_per_slot_synthetic": [round(float(v), 3) for v in metrics.nmse_db(sums)],
         })
         # NMSE on the reference's stored CDL-B sequences next to the NMSE of the reference's own
         # stored outputs for them (CR_data_* -> CR_transformer_*): the accuracy contract.
@@ -295,7 +690,7 @@ def main():
             "reference_nmse_db_per_slot": [round(float(v), 4) for v in nm_ref],
             "max_abs_delta_db": float((nm_ours - nm_ref).abs().max()),
             "max_abs_err_vs_reference_output": float((ours.cpu() - torch.from_numpy(ref_out)).abs().max())}
-        if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
+        if with_cpu:
             # the baseline: stock PyTorch on the host cores (the ATen CPU kernels the reference's own
             # CPU path runs); beside it the same with one thread and the scalar C checker
             from oracle import torch_ref
@@ -307,265 +702,18 @@ def main():
             out["cpu_baseline_other"] = {
                 "torch_one_thread": one,
                 "c_checker": cpu_baseline_informer(ck, x.cpu().numpy(), xd.cpu().numpy(), budget_s=5.0)}
-
         if rank == 0 and n_gpus == 1 and not args.skip_secondary:
-            # secondary lines: the other kernels of the path, shorter runs
-            model2, _ = make_informer(not want_maps)
-            def step2():
-                model2(x, xd)
-            w2, d2 = timed_loop(step2, max(5, args.steps // 5), 2, False, dev)
-            extra[f"informer_output_attention_{not want_maps}"] = {
-                "predictions_per_s": B / d2, "kernel_ms": d2 * 1e3,
-                "mfma_frac": INFORMER_FLOP * B / d2 / 1e12 / PEAK_FP32_MFMA_TFLOPS}
-            # the reference's own GPU path on this card: the model in stock PyTorch-ROCm eager
-            # calls (oracle/torch_ref.py on device tensors), same weights, same batch
-            from oracle import torch_ref as _tr
-            sd_dev = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in ck.items()}
-            def step_eager():
-                with torch.no_grad():
-                    _tr.informer_forward(sd_dev, x, xd, 5)
-            _w, de = timed_loop(step_eager, 10, 3, False, dev)
-            extra["stock_pytorch_rocm_eager_same_gpu"] = {
-                "predictions_per_s": B / de, "step_ms": de * 1e3,
-                "speedup_of_the_hip_kernel": de / dev_s,
-                "note": "InformerStack forward, B=4096, torch.nn.functional calls on the MI355X (about 190 kernel launches)"}
-            del sd_dev
-            # the same step fed from and returning to pinned host memory (Predict.py:99-117
-            # moves every batch numpy -> GPU -> numpy); never the headline value
-            xh, xdh = x.cpu().pin_memory(), xd.cpu().pin_memory()
-            oh = torch.empty(B, 5, 16).pin_memory()
-            def step_host():
-                r = model(xh.to(dev, non_blocking=True), xdh.to(dev, non_blocking=True))
-                oh.copy_(r[0] if want_maps else r, non_blocking=True)
-            _w, dh = timed_loop(step_host, max(5, args.steps // 5), 2, False, dev)
-            extra["informer_with_host_transfers"] = {
-                "predictions_per_s": B / dh, "step_ms": dh * 1e3,
-                "note": "pinned host input (x_enc, x_dec) -> device -> forward -> prediction to pinned host"}
-            N = 1 << 23
-            y, H, _xs = lmmse_inputs(N, 16, 4, 0.1, dev, 0)
-            def step3():
-                cet.lmmse(y, H, 0.1)
-            w3, d3 = timed_loop(step3, 10, 2, False, dev)
-            extra["lmmse_16x4"] = {"REs_per_s": N / d3, "kernel_ms": d3 * 1e3, "N": N,
-                                   "hbm_GBps": 688.0 * N / d3 / 1e9,
-                                   "hbm_frac": 688.0 * N / d3 / 1e9 / PEAK_HBM_GBS}
-            del y, H
-            yb, Hb, _xs = lmmse_inputs(N, 16, 4, 0.1, dev, 0, 14)
-            def step3c():
-                cet.lmmse(yb, Hb, 0.1, h_share=14)
-            _w, db = timed_loop(step3c, 10, 2, False, dev)
-            bpr = 688.0 - 512.0 * 13 / 14
-            extra["lmmse_16x4_block_fading_14"] = {
-                "REs_per_s": N / db, "kernel_ms": db * 1e3, "N": N, "bytes_per_RE": bpr,
-                "hbm_GBps": bpr * N / db / 1e9, "hbm_frac": bpr * N / db / 1e9 / PEAK_HBM_GBS}
-            del yb, Hb
-            # the reference-sized equalizer shapes (4 x 2 of EndtoEndtest.py, 8 x 4)
-            for (nr, ns) in ((8, 4), (4, 2)):
-                Nv = 1 << 24
-                yv, Hv, _xs = lmmse_inputs(Nv, nr, ns, 0.1, dev, 0)
-                def step3b():
-                    cet.lmmse(yv, Hv, 0.1)
-                _w, dv = timed_loop(step3b, 10, 2, False, dev)
-                bpr = LMMSE_BYTES[(nr, ns)]
-                extra[f"lmmse_{nr}x{ns}"] = {"REs_per_s": Nv / dv, "kernel_ms": dv * 1e3, "N": Nv,
-                                             "hbm_GBps": bpr * Nv / dv / 1e9,
-                                             "hbm_frac": bpr * Nv / dv / 1e9 / PEAK_HBM_GBS}
-                del yv, Hv
-            # the reference's receive chain on its own grid (EndtoEndtest.py:50-59, 130-133, 184-191):
-            # LS estimate with nearest-neighbour interpolation -> LMMSEEqualizer object, 4 rx x 2 streams
-            rg = cet.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=1,
-                                  num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
-                                  dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
-            est = cet.LSChannelEstimator(rg, interpolation_type="nn")
-            equ = cet.LMMSEEqualizer(rg, cet.StreamManagement(np.array([[1]]), 2))
-            nb = 8192
-            yg = torch.view_as_complex(torch.randn(nb, 1, 4, 14, 76, 2, device=dev))
-            hold2 = {}
-            def step_ls():
-                hold2["h"], hold2["e"] = est([yg, 0.1])
-            _w, dls = timed_loop(step_ls, 10, 2, False, dev)
-            def step_eq():
-                equ([yg, hold2["h"], hold2["e"], 0.1])
-            _w, deq = timed_loop(step_eq, 10, 2, False, dev)
-            n_out = nb * 4 * 2 * 14 * 64
-            extra["receive_chain_reference_grid"] = {
-                "batch": nb, "ls_nn_ms": dls * 1e3, "ls_nn_GBps": (n_out * 12 + yg.numel() * 8) / dls / 1e9,
-                "equalizer_object_ms": deq * 1e3, "equalizer_object_REs_per_s": nb * 12 * 64 / deq,
-                # per data RE: y 4x8 + h_hat 8x8 + err_var 8x4 + x_hat 2x8 + no_eff 2x4 bytes
-                "equalizer_object_GBps": nb * 12 * 64 * 152.0 / deq / 1e9}
-            del yg, hold2
-            # the reference's own CPU-runnable case: B = 64 (latency-bound on the GPU: 64 waves /
-            # 2 workgroups on a 256-CU chip)
-            x64, xd64 = x[:64].contiguous(), xd[:64].contiguous()
-            def step64():
-                model(x64, xd64)
-            _w, d64 = timed_loop(step64, 20, 3, False, dev)
-            gm, _sd = make_rnn("gru")
-            def step64g():
-                gm.test_data(x64, 5, dev)
-            _w, d64g = timed_loop(step64g, 20, 3, False, dev)
-            extra["batch_64_latency"] = {"informer_ms": d64 * 1e3, "gru_pred5_ms": d64g * 1e3,
-                                         "informer_predictions_per_s": 64 / d64,
-                                         "gru_predictions_per_s": 64 / d64g}
-            for kind in ("lstm", "gru", "rnn"):
-                rm, _sd = make_rnn(kind)
-                nb, _ = synth.channel_histories(8192, seed=1)
-                xr = cet.LoadBatch(nb[:, :25]).to(dev)
-                def step4():
-                    rm.test_data(xr, 5, dev)
-                w4, d4 = timed_loop(step4, 10, 2, False, dev)
-                fl = RNN_FLOP_PER_STEP[kind] * 29 * 8192
-                sd_dev = {k: torch.from_numpy(np.array(v)).to(dev) for k, v in _sd.items()}
-                def step4e():
-                    _tr.rnn_rollout(sd_dev, kind, xr, 5)
-                _w, d4e = timed_loop(step4e, 5, 2, False, dev)
-                extra[f"{kind}_rollout_B8192_pred5"] = {
-                    "predictions_per_s": 8192 / d4, "kernel_ms": d4 * 1e3,
-                    "mfma_frac": fl / d4 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                    "stock_pytorch_rocm_eager_ms": d4e * 1e3, "speedup_of_the_hip_kernel": d4e / d4}
-
+            extra = secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s)
     elif args.workload == "e2e":
-        # Transformer prediction of 5 future slots per subcarrier sample -> LMMSE over the 14
-        # OFDM symbols of each predicted slot (4 receive antennas, 2 streams) -> hard-decision
-        # QPSK bit errors and per-slot NMSE; ranks hold disjoint subcarrier ranges.
-        scaled = args.geometry == "scaled"
-        S = args.batch or 3276 * 8   # predictor sequences per GPU
-        n_sym, no = 14, 0.05
-        Nr, Nt = (16, 4) if scaled else (4, 2)
-        model, ck = make_informer(False)
-        # the checkpoint predicts CDL-B channels: the reference's 192 stored sequences, tiled
-        cr = np.load(os.path.join(GOLDEN, "cr_pairs.npz"))
-        real = np.concatenate([cr["data_30"], cr["data_36"], cr["data_60"]])
-        real = np.roll(real, 7 * rank, axis=0)[np.arange(S) % real.shape[0]]
-        real = torch.from_numpy(real).to(dev).to(torch.complex64)
-        if scaled:  # eight stored 4x2 sequences make one 16x4 subcarrier sample
-            real = e2e.ungroup_antennas(real[:S - S % 8], Nr, Nt)
-        h_hist, h_future = real[:, :25].contiguous(), real[:, 25:30].contiguous()
-        n_sc = h_hist.shape[0]
-        out["data"] = "the reference's stored CDL-B sequences (CR_data_30/36/60), tiled; synthetic QPSK + AWGN"
-        g = torch.Generator(device=dev).manual_seed(rank)
-        y, xs = e2e.transmit(h_future, n_sym, no, g)
-        holder = {}
-
-        def step():
-            if scaled:
-                h_hat = e2e.predict_slots_grouped(model, h_hist, 10, 5)
-            else:
-                h_hat = e2e.predict_slots(model, h_hist, 10, 5)
-            x_hat, _ = e2e.equalize_slots(h_hat, y, no)
-            bits = metrics.qpsk_bit_errors(x_hat, xs)
-            holder["sums"] = {"nmse": metrics.nmse_partial_sums(h_hat, h_future), "bits": bits,
-                              "bits_perfect": bits}  # replaced after the timed region
-
-        wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
-        # outside the timed region: the same link equalized with the true channel, and with the
-        # prediction error's variance passed to the equalizer
-        x_true, _ = e2e.equalize_slots(h_future.to(torch.complex64), y, no)
-        holder["sums"]["bits_perfect"] = metrics.qpsk_bit_errors(x_true, xs)
-        h_hat = (e2e.predict_slots_grouped if scaled else e2e.predict_slots)(model, h_hist, 10, 5)
-        err_var = float((h_hat - h_future).abs().pow(2).mean())
-        x_ev, _ = e2e.equalize_slots(h_hat, y, no, err_var)
-        bits_ev = metrics.qpsk_bit_errors(x_ev, xs)
-        metrics.all_reduce_sums(bits_ev)
-        res = e2e.reduce(holder["sums"])  # the path's only collective (RCCL)
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        if dist_on:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t)
-        n_re = n_sc * 5 * n_sym
-        out.update({
-            "metric": "channel predictions/s (Transformer prediction + LMMSE equalization + BER/NMSE)",
-            "value": S * n_gpus * args.steps / wall, "unit": "predictions/s",
-            "ms_per_step": wall / args.steps * 1e3, "dtype": "f32",
-            "config": {"workload": f"end to end: InformerStack default configuration on {S} 4x2 antenna "
-                                   f"groups = {n_sc} subcarrier samples per GPU ({Nr}x{Nt} channel), "
-                                   f"block-fading LMMSE {Nr}x{Nt} on {n_re} REs "
-                                   f"(5 slots x {n_sym} symbols), QPSK, no={no}",
-                       "parallelism": f"dp{n_gpus} (subcarrier ranges)"},
-            "roofline": {"bound": "mfma", "achieved": INFORMER_FLOP * S / dev_s / 1e12,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": INFORMER_FLOP * S / dev_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "whole step (informer_kernel + lmmse + torch glue)",
-                         "kernel_ms": dev_s * 1e3},
-            "equalized_REs_per_s": n_re * n_gpus * args.steps / wall,
-            "ber": res["ber"], "ber_perfect_csi": res["ber_perfect_csi"],
-            "ber_with_err_var": float(bits_ev[0] / bits_ev[1]), "err_var": err_var,
-            "nmse_db_per_slot": [round(v, 3) for v in res["nmse_db"]],
-        })
-
+        out.update(run_e2e(ctx, args.geometry == "scaled", args.batch or 3276 * 8, args.steps, args.warmup))
     elif args.workload == "lmmse":
-        Nr, Ns, no = 16, 4, 0.1
-        N = args.batch or 3276 * 14 * 1024  # 46,964,736 REs = 32.3 GB of operands
-        hs = max(1, args.h_share)
-        y, H, xs = lmmse_inputs(N, Nr, Ns, no, dev, rank, hs)
-        holder = {}
-
-        def step():
-            holder["x"], holder["ne"] = cet.lmmse(y, H, no, h_share=hs)
-
-        wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
-        bits = metrics.qpsk_bit_errors(holder["x"], xs)
-        metrics.all_reduce_sums(bits)
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        if dist_on:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t)
-        bytes_re = LMMSE_BYTES[(Nr, Ns)] - Nr * Ns * 8 * (1.0 - 1.0 / hs)  # H once per block
-        gbs = bytes_re * N / dev_s / 1e9
-        out.update({
-            "metric": "LMMSE-equalized REs/s", "value": N * n_gpus * args.steps / wall, "unit": "REs/s",
-            "ms_per_step": wall / args.steps * 1e3, "dtype": "complex64 (f32 arithmetic)",
-            "config": {"workload": f"LMMSE {Nr}x{Ns}, {N} REs per GPU (3276 sc x 14 sym x 1024 slots), no=0.1"
-                                   + (f", block fading: one H per {hs} REs, {bytes_re:.1f} B/RE" if hs > 1 else ""),
-                       "parallelism": f"dp{n_gpus}"},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": gbs / PEAK_HBM_GBS,
-                         "traffic": measured_traffic("lmmse", N) if hs == 1 else None,
-                         "kernel": "lmmse_tiled<16,4,2>",
-                         "kernel_ms": dev_s * 1e3, "bytes_per_launch": bytes_re * N},
-            "ber": float(bits[0] / bits[1]),
-        })
-        if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_lmmse(Nr, Ns, no)
-
+        out.update(run_lmmse(ctx, args.batch or 3276 * 14 * 1024, max(1, args.h_share), args.steps,
+                             args.warmup, with_cpu))
+    elif args.workload == "selftest":
+        out.update(run_selftest(ctx))
     else:
-        kind = args.workload
-        B = args.batch or 8192
-        P = args.pred_len
-        model, sd = make_rnn(kind)
-        noisy, _ = synth.channel_histories(B, T=25 + 5, seed=rank)
-        x = cet.LoadBatch(noisy[:, :25]).to(dev)
-        holder = {}
-
-        def step():
-            holder["pred"] = model.test_data(x, P, dev)
-
-        wall, dev_s = timed_loop(step, args.steps, args.warmup, dist_on, dev)
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        if dist_on:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t)
-        flop = RNN_FLOP_PER_STEP[kind] * (24 + P) * B
-        achieved = flop / dev_s / 1e12
-        out.update({
-            "metric": f"channel predictions/s ({kind.upper()} rollout)",
-            "value": B * n_gpus * args.steps / wall, "unit": "predictions/s",
-            "ms_per_step": wall / args.steps * 1e3, "dtype": "f32",
-            "config": {"workload": f"{kind.upper()}(16,16,256,2).test_data, seq_len 25, pred_len {P}, shipped checkpoint",
-                       "batch_per_gpu": B, "global_batch": B * n_gpus, "parallelism": f"dp{n_gpus}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "rnn_rollout_kernel", "kernel_ms": dev_s * 1e3, "flop_per_launch": flop},
-        })
-        if rank == 0 and n_gpus == 1 and not args.skip_cpu_baseline:
-            from oracle import torch_ref
-            xc = x.cpu()
-            out["cpu_baseline"], one = cpu_baseline_torch(
-                lambda n: torch_ref.rnn_rollout(sd, kind, xc[:n], P), B,
-                f"stock torch.nn.{kind.upper()} rollout (oracle/torch_ref.py)")
-            out["cpu_baseline_other"] = {
-                "torch_one_thread": one,
-                "c_checker": cpu_baseline_rnn(kind, sd, x.cpu().numpy(), P, budget_s=5.0)}
+        out.update(run_rnn(ctx, args.workload, args.batch or 8192, args.pred_len, args.steps, args.warmup,
+                           with_cpu))
 
     if extra:
         out["secondary"] = extra

@@ -17,7 +17,8 @@ ERR_NAMES = {0: "CET_OK", 1: "CET_ERR_INVALID_ARG", 2: "CET_ERR_UNSUPPORTED", 3:
 EXPORTS = (
     "cet_strerror", "cet_last_hip_error", "cet_abi_version", "cet_destroy",
     "cet_informer_blob_size", "cet_informer_create", "cet_informer_attn_size",
-    "cet_informer_forward", "cet_informer_taps_size", "cet_informer_forward_taps",
+    "cet_informer_forward", "cet_informer_select", "cet_informer_taps_size",
+    "cet_informer_forward_taps",
     "cet_rnn_blob_size", "cet_rnn_create", "cet_rnn_rollout", "cet_lmmse", "cet_lmmse_direct",
     "cet_lmmse_llr", "cet_lmmse_block", "cet_lmmse_block_llr", "cet_lmmse_grid", "cet_ls_nn", "cet_nmse_sums", "cet_qpsk_bit_errors",
 )
@@ -60,6 +61,7 @@ def lib():
     L.cet_informer_attn_size.restype = ctypes.c_size_t
     L.cet_informer_attn_size.argtypes = [vp, ctypes.c_int]
     L.cet_informer_forward.argtypes = [vp, fp, fp, fp, fp, ctypes.c_int, vp]
+    L.cet_informer_select.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.cet_informer_taps_size.restype = ctypes.c_size_t
     L.cet_informer_taps_size.argtypes = [vp, ctypes.c_int]
     L.cet_informer_forward_taps.argtypes = [vp, fp, fp, fp, fp, fp, ctypes.c_int, vp]

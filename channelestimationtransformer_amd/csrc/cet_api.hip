@@ -20,6 +20,7 @@ int informer_create(const cet_informer_cfg* cfg, const float* w, size_t n, Infor
 void informer_destroy(InformerModel* m);
 size_t informer_attn_size(const InformerModel* m, int B);
 size_t informer_taps_size(const InformerModel* m, int B);
+void informer_select(InformerModel* m, int kernel, int pack);
 int informer_forward(const InformerModel* m, const float* x_enc, const float* x_dec, float* out,
                      float* attn, float* taps, int B, hipStream_t stream);
 
@@ -28,6 +29,14 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
 void rnn_destroy(RnnModel* m);
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream);
+
+// A handle's weights live on the device that was current when it was created; launching from
+// another device would read them across GPUs (or fault without peer access).
+static int check_device(const cet_handle_s* h) {
+  int dev = -1;
+  CET_HIP(hipGetDevice(&dev));
+  return dev == h->device ? CET_OK : CET_ERR_INVALID_ARG;
+}
 
 }  // namespace cet
 
@@ -38,7 +47,8 @@ extern "C" {
 const char* cet_strerror(int code) {
   switch (code) {
     case CET_OK: return "success";
-    case CET_ERR_INVALID_ARG: return "invalid argument";
+    case CET_ERR_INVALID_ARG:
+      return "invalid argument (null pointer, bad size or enum, or the handle belongs to another device)";
     case CET_ERR_UNSUPPORTED: return "configuration not supported by the gfx950 kernels";
     case CET_ERR_HIP: return "HIP runtime call failed";
     case CET_ERR_ALLOC: return "allocation failed";
@@ -102,8 +112,16 @@ int cet_informer_forward_taps(cet_handle h, const float* x_enc, const float* x_d
   if (!h || h->kind != HANDLE_INFORMER || B < 0) return CET_ERR_INVALID_ARG;
   if (B == 0) return CET_OK;
   if (!x_enc || !x_dec || !out) return CET_ERR_INVALID_ARG;
+  if (const int rc = check_device(h)) return rc;
   return informer_forward(static_cast<InformerModel*>(h->impl), x_enc, x_dec, out, attn, taps, B,
                           static_cast<hipStream_t>(stream));
+}
+
+int cet_informer_select(cet_handle h, int kernel, int pack) {
+  if (!h || h->kind != HANDLE_INFORMER || kernel < -1 || kernel > 2 || pack < -1 || pack > 1)
+    return CET_ERR_INVALID_ARG;
+  informer_select(static_cast<InformerModel*>(h->impl), kernel, pack);
+  return CET_OK;
 }
 
 int cet_informer_forward(cet_handle h, const float* x_enc, const float* x_dec, float* out,
@@ -141,6 +159,7 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
     return CET_ERR_INVALID_ARG;
   if (B == 0) return CET_OK;
   if (!x || !out) return CET_ERR_INVALID_ARG;
+  if (const int rc = check_device(h)) return rc;
   return rnn_rollout(static_cast<RnnModel*>(h->impl), x, out, B, seq_len, pred_len,
                      static_cast<hipStream_t>(stream));
 }

@@ -78,7 +78,9 @@ struct KArgs {
   int n_ops, n_ops2;  // encoder steps; the first n_ops2 of them touch more than 16 rows
   int mem_rows;
   Op ops[MAX_OPS];
-  int ablate;       // timing experiments only (CET_INFORMER_ABLATE): skips parts, wrong results
+#ifdef CET_EXP
+  int ablate;       // experiment build only (CET_INFORMER_ABLATE): skips parts, wrong results
+#endif
   const float* wblk;    // workgroup kernel: staged Linear blocks in consumption order
   int n_blk;
   int wave_lds_floats;  // LDS floats private to a wave
@@ -146,15 +148,25 @@ DEV float group_max(float v) {
 struct Lane {
   int c;  // lane & 15 : row inside a tile (B operand / C column)
   int g;  // lane >> 4 : k group / C row block
-  int ablate;  // timing-experiment mask, 0 in production
   unsigned wo;  // c * 64 + 4 * g : this lane's offset inside a 16-row block of a [.][64] matrix
   float inv_n, pad_n;  // LayerNorm over the real features: 1 / d_model, 64 - d_model
   float attn_c;        // softmax scale times log2(e)
+#ifdef CET_EXP
+  int ablate;  // experiment build only: mask of the parts to skip
+#endif
 #ifdef CET_PROF
   unsigned long long* prof;  // this wave's stamp trace, or null when the wave is not sampled
   int* pidx;                 // next free entry of the trace
 #endif
 };
+
+// Timing experiments that skip parts of the arithmetic exist in the experiment build only
+// (make libcet_exp.so EXP="-DCET_EXP"); in the product library the tests fold to false.
+#ifdef CET_EXP
+#define ABLATED(holder, bit) (((holder).ablate & (bit)) != 0)
+#else
+#define ABLATED(holder, bit) false
+#endif
 
 // Phase stamps of the profiling build (libcet_prof.so): a few sampled waves append
 // (clock << 4 | category) to a trace in global memory; the host sums the intervals per
@@ -330,7 +342,7 @@ DEV void store_rows(float* buf, const Lane ln, const f32x4 (&v)[2][4], int nrows
 // torch.nn.LayerNorm(64), eps 1e-5, over the feature axis (in-lane 16 values + lane groups).
 template <int RT>
 DEV void layer_norm(f32x4 (&x)[2][4], const NormParams& n, const Lane ln) {
-  if (ln.ablate & 16) return;
+  if (ABLATED(ln, 16)) return;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     // sums are kept four wide (packed fp32 adds / FMAs) and folded at the end
@@ -533,7 +545,7 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
             const f32x4 d = p[pi][hh][kt][qt] - mx[pi][hh][qt];
             f32x4 e;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) e[i] = (ln.ablate & 4) ? d[i] : __builtin_amdgcn_exp2f(d[i]);
+            for (int i = 0; i < 4; ++i) e[i] = ABLATED(ln, 4) ? d[i] : __builtin_amdgcn_exp2f(d[i]);
             p[pi][hh][kt][qt] = e;
             sm += e;
           }
@@ -1069,7 +1081,7 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
       cu.attn += (size_t)a.B * NHEAD * L * L;
     }
     encoder_layer<RT, WG>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
-    if (!(a.ablate & 8)) cu.w += SZ_ENC_LAYER;
+    if (!ABLATED(a, 8)) cu.w += SZ_ENC_LAYER;
     tap<RT>(cu.taps, a.B, b, L, ln, x);
   } else if (op.type == OP_DISTIL) {
     const int Lo = distil<RT, WG>(cu.w, st, smem, R, ln, L, x);
@@ -1173,13 +1185,17 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   const int prof_stride = a.B >= PROF_SAMPLES ? a.B / PROF_SAMPLES : 1;
   const int prof_slot = seq / prof_stride;
   const bool prof_on = valid && seq % prof_stride == 0 && prof_slot < PROF_SAMPLES;
-  const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)),
-                a.ln_inv_n, a.ln_pad, a.attn_c,
-                prof_on ? a.prof + (size_t)prof_slot * PROF_MAXM : nullptr, &prof_idx};
+  Lane ln{lane & 15, lane >> 4, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)), a.ln_inv_n, a.ln_pad,
+          a.attn_c};
+  ln.prof = prof_on ? a.prof + (size_t)prof_slot * PROF_MAXM : nullptr;
+  ln.pidx = &prof_idx;
   PROF_MARK(ln, P_OTHER);
 #else
-  const Lane ln{lane & 15, lane >> 4, a.ablate, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)),
-                a.ln_inv_n, a.ln_pad, a.attn_c};
+  Lane ln{lane & 15, lane >> 4, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)), a.ln_inv_n, a.ln_pad,
+          a.attn_c};
+#endif
+#ifdef CET_EXP
+  ln.ablate = a.ablate;
 #endif
   Stage st{a.wblk, smem_all, WG ? lds_address(smem_all) : 0u, 0, WG ? a.n_blk : 0, wave, lane};
   if (WG) stage_request(st);  // block 0 travels while the embedding is computed
@@ -1253,7 +1269,7 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   }
   for (int l = 0; l < a.d_layers; ++l) {
     decoder_layer<RD, RM, WG>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
-    if (!(a.ablate & 8)) cu.w += SZ_DEC_LAYER;
+    if (!ABLATED(a, 8)) cu.w += SZ_DEC_LAYER;
     tap<RD>(cu.taps, a.B, b, Ld, ln, x);
   }
   layer_norm<RD>(x, cu.w, cu.w + DM, ln);
@@ -1300,6 +1316,14 @@ struct InformerModel {
   int n_blocks = 0;
   size_t attn_per_sample = 0;  // floats
   size_t taps_per_sample = 0;
+  int device = 0;  // the HIP device that holds the weights
+  int cus = 0;     // its compute units
+  // Launch shape: 0 = by batch size, 1 = one wave per sequence, 2 = workgroups of 8 sequences;
+  // pack = two sequences per tile in the short encoder stages of the workgroup kernel. Set at
+  // create time (CET_INFORMER_KERNEL / CET_INFORMER_PACK in the environment) or through
+  // cet_informer_select; never read from the environment in the launch path.
+  int kernel_choice = 0;
+  bool pack = true;
 };
 
 static bool supported(const cet_informer_cfg& c) {
@@ -1585,7 +1609,16 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   for (int i = 0; i < d.n_attn; ++i) m->attn_per_sample += (size_t)NHEAD * d.attn_len[i] * d.attn_len[i];
   for (int i = 0; i < d.n_taps; ++i) m->taps_per_sample += (size_t)d.tap_rows[i] * DM;
   m->n_blocks = (int)(blk.size() / WBLK);
-  hipError_t e = hipMalloc(&m->dev_blob, v.size() * sizeof(float));
+  if (const char* k = getenv("CET_INFORMER_KERNEL")) m->kernel_choice = k[0] == 'o' ? 1 : (k[0] == 'w' ? 2 : 0);
+  if (const char* k = getenv("CET_INFORMER_PACK")) m->pack = k[0] != '0';
+  hipError_t e = hipGetDevice(&m->device);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&m->cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  // the workgroup kernel's dynamic LDS exceeds the default limit: raised once per device, here
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<1, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipMalloc(&m->dev_blob, v.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(m->dev_blob, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&m->dev_blocks, blk.size() * sizeof(float));
@@ -1606,6 +1639,12 @@ void informer_destroy(InformerModel* m) {
   if (m->dev_blob) (void)hipFree(m->dev_blob);
   if (m->dev_blocks) (void)hipFree(m->dev_blocks);
   delete m;
+}
+
+int informer_device(const InformerModel* m) { return m->device; }
+void informer_select(InformerModel* m, int kernel, int pack) {
+  if (kernel >= 0) m->kernel_choice = kernel;
+  if (pack >= 0) m->pack = pack != 0;
 }
 
 size_t informer_attn_size(const InformerModel* m, int B) { return m->attn_per_sample * (size_t)B; }
@@ -1660,8 +1699,7 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
       p0 = k;
     }
     while (p0 < n && a.ops[p0].type != OP_LAYER) ++p0;  // start at a layer
-    const char* pk = getenv("CET_INFORMER_PACK");       // "0" disables (tests, timing)
-    a.n_pack0 = (pk && pk[0] == '0') ? n : p0;
+    a.n_pack0 = m->pack ? p0 : n;
   }
   // LDS of a wave. One-wave kernel: three regions of R rows (Q | K | V), which also cover the
   // conv / max-pool staging (L + (L + 2) rows) and the staging of move_rows. Workgroup kernel:
@@ -1676,15 +1714,14 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   a.attn_c = (float)(1.0 / sqrt((double)(m->cfg.d_model / NHEAD))) * 1.44269504088896340736f;
   a.wblk = m->dev_blocks;
   a.n_blk = m->n_blocks;
+#ifdef CET_EXP
   static const int ablate = [] {
     const char* e = getenv("CET_INFORMER_ABLATE");
     return e ? atoi(e) : 0;
   }();
   a.ablate = ablate;
-  // CET_INFORMER_KERNEL=one_wave | workgroup overrides the choice below (tests, timing); read
-  // on every call so that a test can switch between the two.
-  const char* force = getenv("CET_INFORMER_KERNEL");
-  const bool force_one = force && force[0] == 'o', force_wg = force && force[0] == 'w';
+#endif
+  const bool force_one = m->kernel_choice == 1, force_wg = m->kernel_choice == 2;
   // Packed tiles are whole 16-row tiles: K | V regions of at least 16 rows, and the packed
   // conv staging of 16 + 32 rows. Where that does not fit, the workgroup kernel runs unpacked.
   int R_wg = R, wg_rows = 2 * R + 2;
@@ -1704,13 +1741,7 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   // 8 x CUs sequences; the one-wave kernel spreads single waves over all CUs and finishes sooner
   // as long as every SIMD holds at most one of them (measured: 0.23 vs 0.27 ms at 4 sequences
   // per CU, 0.32 vs 0.28 ms at 5).
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    CET_HIP(hipGetDevice(&dev));
-    CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  const bool wg = wg_lds <= 160 * 1024 && !force_one && (force_wg || B > 4 * cus);
+  const bool wg = wg_lds <= 160 * 1024 && !force_one && (force_wg || B > 4 * m->cus);
 #ifdef CET_PROF
   static unsigned long long* prof_dev = nullptr;
   const size_t prof_bytes = (size_t)PROF_SAMPLES * PROF_MAXM * sizeof(unsigned long long);
@@ -1723,18 +1754,8 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     a.wave_lds_floats = (int)(wg_wave_bytes / sizeof(float));
     a.region_rows = R_wg;
     const dim3 grid((unsigned)((B + WG_WAVES - 1) / WG_WAVES)), block(64 * WG_WAVES);
-#define CET_LAUNCH_WG(RD_, RM_)                                                                  \
-  do {                                                                                           \
-    static bool attr_set[64] = {};                                                               \
-    int dev = 0;                                                                                 \
-    CET_HIP(hipGetDevice(&dev));                                                                 \
-    if (dev < 64 && !attr_set[dev]) {                                                            \
-      CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<RD_, RM_, true>), \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
-      attr_set[dev] = true;                                                                      \
-    }                                                                                            \
-    hipLaunchKernelGGL((informer_kernel<RD_, RM_, true>), grid, block, wg_lds, stream, a);       \
-  } while (0)
+#define CET_LAUNCH_WG(RD_, RM_) \
+  hipLaunchKernelGGL((informer_kernel<RD_, RM_, true>), grid, block, wg_lds, stream, a)
     if (!d2 && !m2) CET_LAUNCH_WG(1, 1);
     else if (!d2 && m2) CET_LAUNCH_WG(1, 2);
     else if (d2 && !m2) CET_LAUNCH_WG(2, 1);

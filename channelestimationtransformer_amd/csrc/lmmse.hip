@@ -28,6 +28,8 @@
 // no_eff = t/(1-t), t = no*(A'^-1)_ss: no cancellation in no_eff at high SNR.
 #include <cstdlib>
 
+#include <atomic>
+
 #include "cet_internal.h"
 
 namespace cet {
@@ -921,12 +923,14 @@ int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, 
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per CU
-  static int per_cu = 0;
+  static std::atomic<int> per_cu_cached{0};  // a property of the kernel's registers and LDS
+  int per_cu = per_cu_cached.load(std::memory_order_relaxed);
   if (!per_cu) {
     int nb = 0;
     CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, reinterpret_cast<const void*>(&lmmse_block<NR, NS, LPR>), 64, 0));
     per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+    per_cu_cached.store(per_cu, std::memory_order_relaxed);
   }
   long grid = (long)cus * per_cu;
   if (grid > n_tiles) grid = n_tiles;
@@ -945,12 +949,14 @@ int launch_tiled(const float* y, const float* H, int no_mode, float no_scalar, c
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per CU
-  static int per_cu = 0;
+  static std::atomic<int> per_cu_cached{0};  // a property of the kernel's registers and LDS
+  int per_cu = per_cu_cached.load(std::memory_order_relaxed);
   if (!per_cu) {
     int nb = 0;
     CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, reinterpret_cast<const void*>(&lmmse_tiled<NR, NS, LPR, false>), 64, 0));
     per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+    per_cu_cached.store(per_cu, std::memory_order_relaxed);
   }
   long grid = (long)cus * per_cu;
   if (grid > n_tiles) grid = n_tiles;
@@ -998,18 +1004,18 @@ int dispatch(const float* y, const float* H, int no_mode, float no_scalar, const
   if (variant == 1 || no_mode == CET_NO_PER_RE_RX)
     return launch_direct<NR, NS>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);
   constexpr int LPR = lanes_per_re<NR, NS>();
+  // block fading with scalar noise: shared factorisation; the other noise modes run the per-RE
+  // kernel with gathered matrices (the two are each other's cross-check)
+  if (hshare > 1 && no_mode == CET_NO_SCALAR)
+    return launch_block<NR, NS, LPR>(y, H, no_scalar, x_hat, no_eff, N, hshare, stream);
+#ifdef CET_EXP  // experiment build only: one lane per RE instead of two (CET_LMMSE_LPR=1)
   static const int lpr_override = [] {
-    const char* e = getenv("CET_LMMSE_LPR");  // timing experiments only
+    const char* e = getenv("CET_LMMSE_LPR");
     return e ? atoi(e) : 0;
   }();
-  // block fading with scalar noise: shared factorisation, unless CET_LMMSE_BLOCK=gather asks for
-  // the per-RE kernel with gathered matrices (the cross-check of the two)
-  const char* blk_env = getenv("CET_LMMSE_BLOCK");  // read per call: tests switch it
-  const bool gather = blk_env && blk_env[0] == 'g';
-  if (hshare > 1 && no_mode == CET_NO_SCALAR && !gather)
-    return launch_block<NR, NS, LPR>(y, H, no_scalar, x_hat, no_eff, N, hshare, stream);
   if (LPR == 2 && lpr_override == 1)
     return launch_tiled<NR, NS, 1>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);
+#endif
   return launch_tiled<NR, NS, LPR>(y, H, no_mode, no_scalar, no_dev, x_hat, no_eff, N, hshare, stream);
 }
 

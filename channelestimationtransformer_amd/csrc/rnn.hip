@@ -441,6 +441,8 @@ struct RnnModel {
   const float *wstream, *bias, *enc_w, *enc_b, *dec_w, *dec_b;
 };
 
+static int rnn_prepare(const RnnModel* m);  // per-device kernel attributes, defined with the launchers
+
 static int gates_of(int kind) { return kind == CET_RNN_TANH ? 1 : (kind == CET_RNN_GRU ? 3 : 4); }
 
 static bool rnn_supported(int kind, int F, int I, int H, int layers) {
@@ -450,6 +452,12 @@ static bool rnn_supported(int kind, int F, int I, int H, int layers) {
   if (F < 4 || F > FP || F % 4) return false;
   if (I < 1 || I > FP) return false;
   return true;
+}
+
+void rnn_destroy(RnnModel* m) {
+  if (!m) return;
+  if (m->dev) (void)hipFree(m->dev);
+  delete m;
 }
 
 size_t rnn_blob_size(int kind, int F, int I, int H, int layers) {
@@ -543,39 +551,70 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   m->wstream = m->dev + o_stream; m->bias = m->dev + o_bias; m->enc_w = m->dev + o_ew;
   m->enc_b = m->dev + o_eb; m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
+  if (const int rc = rnn_prepare(m)) {
+    rnn_destroy(m);
+    return rc;
+  }
   *out = m;
   return CET_OK;
 }
 
-void rnn_destroy(RnnModel* m) {
-  if (!m) return;
-  if (m->dev) (void)hipFree(m->dev);
-  delete m;
+
+template <int KIND, int UT, int NL>
+static size_t lds_bytes() {
+  constexpr int H = 128 * UT;
+  return sizeof(float) * (size_t)(BT * PSTR * 5 + NL * BT * (H + 4) + NL * 2 * Cell<KIND>::G * H +
+                                  FP * PSTR + FP);
+}
+
+// Once per handle, on the handle's device: the kernel's dynamic LDS exceeds the default limit.
+template <int KIND, int UT, int NL>
+static int prepare() {
+  CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_rollout_kernel<KIND, UT, NL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes<KIND, UT, NL>()));
+  return CET_OK;
 }
 
 template <int KIND, int UT, int NL>
 static int launch(const RArgs& a, hipStream_t stream) {
-  constexpr int H = 128 * UT;
-  const size_t lds = sizeof(float) * (size_t)(BT * PSTR * 5 + NL * BT * (H + 4) +
-                                              NL * 2 * Cell<KIND>::G * H + FP * PSTR + FP);
-  CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_rollout_kernel<KIND, UT, NL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((a.B + BT - 1) / BT);
+  const size_t lds = lds_bytes<KIND, UT, NL>();
   hipLaunchKernelGGL((rnn_rollout_kernel<KIND, UT, NL>), dim3(grid), dim3(256), lds, stream, a);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
 
+// The instantiation that serves a model: (cell kind, H / 128, layers).
+typedef int (*PrepareFn)();
+typedef int (*LaunchFn)(const RArgs&, hipStream_t);
 template <int KIND>
-static int launch_kind(const RnnModel* m, const RArgs& a, hipStream_t s) {
-  const int ut = m->H / 128;
-  if (ut == 1 && m->layers == 1) return launch<KIND, 1, 1>(a, s);
-  if (ut == 1 && m->layers == 2) return launch<KIND, 1, 2>(a, s);
-  if (ut == 1 && m->layers == 3) return launch<KIND, 1, 3>(a, s);
-  if (ut == 2 && m->layers == 1) return launch<KIND, 2, 1>(a, s);
-  if (ut == 2 && m->layers == 2) return launch<KIND, 2, 2>(a, s);
-  if (ut == 2 && m->layers == 3) return launch<KIND, 2, 3>(a, s);
-  return CET_ERR_UNSUPPORTED;
+static bool variant_of_kind(int ut, int layers, PrepareFn* pf, LaunchFn* lf) {
+#define CET_RNN_CASE(UT_, NL_)                 \
+  if (ut == UT_ && layers == NL_) {            \
+    *pf = &prepare<KIND, UT_, NL_>;            \
+    *lf = &launch<KIND, UT_, NL_>;             \
+    return true;                               \
+  }
+  CET_RNN_CASE(1, 1) CET_RNN_CASE(1, 2) CET_RNN_CASE(1, 3)
+  CET_RNN_CASE(2, 1) CET_RNN_CASE(2, 2) CET_RNN_CASE(2, 3)
+#undef CET_RNN_CASE
+  return false;
+}
+static bool variant(int kind, int ut, int layers, PrepareFn* pf, LaunchFn* lf) {
+  switch (kind) {
+    case CET_RNN_TANH: return variant_of_kind<CET_RNN_TANH>(ut, layers, pf, lf);
+    case CET_RNN_GRU: return variant_of_kind<CET_RNN_GRU>(ut, layers, pf, lf);
+    case CET_RNN_LSTM: return variant_of_kind<CET_RNN_LSTM>(ut, layers, pf, lf);
+    default: return false;
+  }
+}
+
+static int rnn_prepare(const RnnModel* m) {
+  PrepareFn pf;
+  LaunchFn lf;
+  if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
+  return pf();
 }
 
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
@@ -591,12 +630,10 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   CET_HIP(hipMemsetAsync(prof_dev, 0, prof_bytes, stream));
   a.prof = prof_dev;
 #endif
-  int rc;
-  switch (m->kind) {
-    case CET_RNN_TANH: rc = launch_kind<CET_RNN_TANH>(m, a, stream); break;
-    case CET_RNN_GRU: rc = launch_kind<CET_RNN_GRU>(m, a, stream); break;
-    default: rc = launch_kind<CET_RNN_LSTM>(m, a, stream); break;
-  }
+  PrepareFn pf;
+  LaunchFn lf;
+  if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
+  const int rc = lf(a, stream);
 #ifdef CET_PROF
   if (rc == CET_OK) {
     static const char* names[RP_CATS] = {"encoder+barrier", "bias init", "x part", "h part",

@@ -33,7 +33,28 @@ class _DeviceWeights(nn.Module):
     def __init__(self):
         super().__init__()
         self._weights_version = 0
-        self._handles = {}  # device index -> (version, handle, extra)
+        self._handles = {}  # device index -> (version, handle as int, extra)
+
+    # A copy of the module must not share the handle cache: every holder of the dict would free
+    # the same handles in __del__. `copy.copy`, `copy.deepcopy`, pickling and
+    # `nn.Module._replicate_for_data_parallel` (torch.nn.DataParallel, HPC/python/Evaluate.py:74)
+    # all start the copy with an empty cache; it packs its own weights on first use.
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handles"] = {}
+        return state
+
+    def __copy__(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__getstate__())
+        for name in ("_parameters", "_buffers", "_modules"):
+            new.__dict__[name] = self.__dict__[name].copy()
+        return new
+
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica._handles = {}
+        return replica
 
     def refresh_weights(self):
         self._weights_version += 1
@@ -63,17 +84,19 @@ class _DeviceWeights(nn.Module):
         if cached is not None and cached[0] == self._weights_version:
             return cached[1], cached[2]
         if cached is not None:
-            _cabi.lib().cet_destroy(cached[1])
             del self._handles[key]
+            _cabi.lib().cet_destroy(ctypes.c_void_p(cached[1]))
         with torch.cuda.device(key):
             handle, extra = self._create(key)
-        self._handles[key] = (self._weights_version, handle, extra)
-        return handle, extra
+        self._handles[key] = (self._weights_version, int(handle.value), extra)
+        return int(handle.value), extra
 
     def __del__(self):
         try:
-            for _, h, _x in self._handles.values():
-                _cabi.lib().cet_destroy(h)
+            handles = self.__dict__.get("_handles") or {}
+            while handles:
+                _, (_v, h, _x) = handles.popitem()
+                _cabi.lib().cet_destroy(ctypes.c_void_p(h))
         except Exception:
             pass
 
@@ -154,6 +177,7 @@ class _InformerBase(_DeviceWeights):
         self._cfg = blobs.make_informer_cfg(enc_in, dec_in, c_out, seq_len, label_len, out_len,
                                             d_model, n_heads, e_layers, d_layers, d_ff,
                                             self._stack, distil, activation)
+        self._kernel_choice = (-1, -1)
         self.enc_embedding = _embedding_holder(enc_in, d_model)
         self.dec_embedding = _embedding_holder(dec_in, d_model)
         depths = blobs.encoder_depths(e_layers, self._stack)
@@ -182,7 +206,22 @@ class _InformerBase(_DeviceWeights):
         rc = L.cet_informer_create(ctypes.byref(self._cfg), blob.ctypes.data_as(ctypes.c_void_p),
                                    blob.size, ctypes.byref(h))
         _cabi.check(rc, "cet_informer_create")
+        if self._kernel_choice != (-1, -1):
+            _cabi.check(L.cet_informer_select(h, *self._kernel_choice), "cet_informer_select")
         return h, L.cet_informer_attn_size(h, 1)
+
+    _KERNELS = {None: -1, "auto": 0, "one_wave": 1, "workgroup": 2}
+
+    def select_kernel(self, kernel=None, pack=None):
+        """Pins the launch shape of the Transformer kernel (tests, timing): kernel "auto" |
+        "one_wave" | "workgroup", pack True/False = two sequences per tile in the short encoder
+        stages of the workgroup kernel; None leaves a setting unchanged. The library picks by
+        batch size by default."""
+        choice = (self._KERNELS[kernel], -1 if pack is None else int(bool(pack)))
+        self._kernel_choice = tuple(c if c >= 0 else old for c, old in zip(choice, self._kernel_choice))
+        for _v, h, _x in self._handles.values():
+            _cabi.check(_cabi.lib().cet_informer_select(ctypes.c_void_p(h), *choice), "cet_informer_select")
+        return self
 
     # -- the reference's call signature ---------------------------------------------------
     def forward(self, x_enc, x_dec, enc_self_mask=None, dec_self_mask=None, dec_enc_mask=None):
@@ -201,7 +240,7 @@ class _InformerBase(_DeviceWeights):
             raise RuntimeError("x_enc is on the CPU: this implementation runs on ROCm GPUs only")
         handle, per_sample = self._handle_for(x_enc.device)
         want = per_sample if self.output_attention else 0
-        pred, attn = torch.ops.cet.informer_forward(x_enc, x_dec, handle.value, c.pred_len,
+        pred, attn = torch.ops.cet.informer_forward(x_enc, x_dec, handle, c.pred_len,
                                                     c.c_out, want)
         if not self.output_attention:
             return pred
@@ -283,27 +322,15 @@ class _RecurrentBase(_DeviceWeights):
             raise RuntimeError(f"x must be [B, seq_len, {self.features}], got {tuple(x.shape)}")
         if not x.is_cuda:
             raise RuntimeError("x is on the CPU: this implementation runs on ROCm GPUs only")
-        return torch.ops.cet.rnn_rollout(x, self._handle_for(x.device)[0].value, int(pred_len))
+        return torch.ops.cet.rnn_rollout(x, self._handle_for(x.device)[0], int(pred_len))
 
     def train_data(self, x, device=None):
-        """Teacher-forced pass used by the reference's training loop (LocalSimulations/models/
-        model.py:285-297, 360-372, 435-447; caller HPC/python/utils.py:191): `[B, seq_len,
-        features]` -> the one-step-ahead output of every step, `[B, seq_len, features]`. Training
-        is not part of the accelerated path: this runs the stock torch modules that hold the
-        parameters (so autograd works, on whatever device `x` and the parameters live), not the
-        HIP rollout kernel."""
-        unit = self.model
-        cell = getattr(unit, self._cell)
-        B = x.shape[0]
-        state = x.new_zeros(self.num_layers, B, self.hidden_size)
-        if self._cell == "lstm":
-            state = (state, state.clone())
-        outputs = []
-        for idx in range(x.shape[1]):
-            step = unit.encoder(x[:, idx:idx + 1].permute(1, 0, 2).contiguous())
-            step, state = cell(step, state)
-            outputs.append(unit.decoder(step))
-        return torch.cat(outputs, dim=0).permute(1, 0, 2).contiguous()
+        """Training is outside this inference path: the two teacher-forced variants of the
+        reference (LocalSimulations/models/model.py:285-297 and the output-aligned one of
+        HPC/python/models/model.py:285-296) are not provided."""
+        raise NotImplementedError(
+            "train_data belongs to the reference's training loops, which this inference-only "
+            "path does not provide; train with the reference and load the checkpoint here")
 
 
 class RNN(_RecurrentBase):

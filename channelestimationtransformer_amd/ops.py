@@ -25,6 +25,27 @@ def _dev_check(*tensors):
     return dev
 
 
+def _f32(name, t, *shape):
+    """A contiguous float32 tensor of exactly this shape (None = any size in that position):
+    the kernels index raw pointers, so a wrong dtype or a short buffer would read out of bounds."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    if t.dim() != len(shape) or any(s is not None and int(d) != int(s) for d, s in zip(t.shape, shape)):
+        raise RuntimeError(f"{name} must have shape {list(shape)}, got {list(t.shape)}")
+    return t.contiguous()
+
+
+def _noise(no, no_mode, N, Nr):
+    """The noise operand of the per-resource-element kernels for `no_mode`."""
+    if no_mode == 0:
+        return None
+    if no_mode == 1:
+        return _f32("no", no, N)
+    if no_mode == 2:
+        return _f32("no", no, N, Nr)
+    raise RuntimeError(f"no_mode must be 0, 1 or 2, got {no_mode}")
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
 
@@ -75,14 +96,15 @@ def lmmse(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: float,
           no_mode: int, direct: bool, h_share: int = 1) -> tuple[torch.Tensor, torch.Tensor]:
     """y [N,Nr,2], H [ceil(N/h_share),Nr,Ns,2] float32 (interleaved complex) -> x_hat [N,Ns,2],
     no_eff [N,Ns]. h_share > 1: block fading, RE n uses H[n // h_share]."""
-    dev = _dev_check(y, H)
-    y = y.contiguous()
-    H = H.contiguous()
-    N, Nr, Ns = y.shape[0], H.shape[1], H.shape[2]
+    dev = _dev_check(y, H) if no_mode == 0 else _dev_check(y, H, no)
+    y = _f32("y", y, None, None, 2)
+    N, Nr = y.shape[0], y.shape[1]
+    H = _f32("H", H, None, Nr, None, 2)
+    Ns = H.shape[2]
     _block_check(N, H.shape[0], h_share, direct)
     x_hat = torch.empty((N, Ns, 2), dtype=torch.float32, device=dev)
     no_eff = torch.empty((N, Ns), dtype=torch.float32, device=dev)
-    no_dev = no.contiguous() if no_mode != 0 else None
+    no_dev = _noise(no, no_mode, N, Nr)
     L = _cabi.lib()
     with torch.cuda.device(dev):
         if h_share > 1:
@@ -155,13 +177,14 @@ def lmmse_llr(y: torch.Tensor, H: torch.Tensor, no: torch.Tensor, no_scalar: flo
               no_mode: int, h_share: int = 1) -> torch.Tensor:
     """y [N,Nr,2], H [ceil(N/h_share),Nr,Ns,2] float32 -> QPSK bit LLRs [N,Ns,2] (equalizer +
     demapper fused)."""
-    dev = _dev_check(y, H)
-    y = y.contiguous()
-    H = H.contiguous()
-    N, Nr, Ns = y.shape[0], H.shape[1], H.shape[2]
+    dev = _dev_check(y, H) if no_mode == 0 else _dev_check(y, H, no)
+    y = _f32("y", y, None, None, 2)
+    N, Nr = y.shape[0], y.shape[1]
+    H = _f32("H", H, None, Nr, None, 2)
+    Ns = H.shape[2]
     _block_check(N, H.shape[0], h_share)
     llr = torch.empty((N, Ns, 2), dtype=torch.float32, device=dev)
-    no_dev = no.contiguous() if no_mode != 0 else None
+    no_dev = _noise(no, no_mode, N, Nr)
     L = _cabi.lib()
     with torch.cuda.device(dev):
         if h_share > 1:
@@ -187,9 +210,14 @@ def ls_nn(y: torch.Tensor, src: torch.Tensor, pinv: torch.Tensor, pabs2inv: torc
     """y [planes, plane, 2] float32 (interleaved complex), tables of T entries ->
     h_hat [planes, T, 2], err_var [planes, T]."""
     dev = _dev_check(y, src, pinv, pabs2inv)
-    y = y.contiguous()
+    y = _f32("y", y, None, None, 2)
     planes, plane = y.shape[0], y.shape[1]
     T = src.numel()
+    if src.dtype != torch.int32 or src.dim() != 1:
+        raise RuntimeError(f"src must be a 1-d int32 table, got {src.dtype} {list(src.shape)}")
+    src = src.contiguous()
+    pinv = _f32("pinv", pinv, T, 2)
+    pabs2inv = _f32("pabs2inv", pabs2inv, T)
     h_hat = torch.empty((planes, T, 2), dtype=torch.float32, device=dev)
     err_var = torch.empty((planes, T), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -213,19 +241,29 @@ def lmmse_grid(y: torch.Tensor, h_hat: torch.Tensor, err_var: torch.Tensor, no: 
     empty or [B,Nr,Ns,n_sym,n_sc]; index tables int32 -> x_hat [B,Ns,n_ds*n_sc,2], no_eff
     [B,Ns,n_ds*n_sc]."""
     dev = _dev_check(y, h_hat, data_sym, eff_sc)
-    y = y.contiguous()
-    h_hat = h_hat.contiguous()
+    y = _f32("y", y, None, None, None, None, 2)
     B, Nr, n_sym, fft = y.shape[:4]
+    h_hat = _f32("h_hat", h_hat, B, Nr, None, n_sym, None, 2)
     Ns, n_sc = h_hat.shape[2], h_hat.shape[4]
     n_ds = data_sym.numel()
-    if tuple(h_hat.shape[:5]) != (B, Nr, Ns, n_sym, n_sc) or eff_sc.numel() != n_sc:
-        raise RuntimeError(f"inconsistent shapes: y {tuple(y.shape)}, h_hat {tuple(h_hat.shape)}")
-    ev = err_var.contiguous() if err_var.numel() else None
-    if ev is not None and tuple(ev.shape) != (B, Nr, Ns, n_sym, n_sc):
-        raise RuntimeError(f"err_var must match h_hat, got {tuple(ev.shape)}")
+    for name, t in (("data_sym", data_sym), ("eff_sc", eff_sc)):
+        if t.dtype != torch.int32 or t.dim() != 1:
+            raise RuntimeError(f"{name} must be a 1-d int32 table, got {t.dtype} {list(t.shape)}")
+    data_sym, eff_sc = data_sym.contiguous(), eff_sc.contiguous()
+    if eff_sc.numel() != n_sc or n_sc > fft or n_ds > n_sym:
+        raise RuntimeError(f"inconsistent shapes: y {tuple(y.shape)}, h_hat {tuple(h_hat.shape)}, "
+                           f"{n_ds} data symbols, {eff_sc.numel()} effective subcarriers")
+    ev = _f32("err_var", err_var, B, Nr, Ns, n_sym, n_sc) if err_var.numel() else None
+    if ev is not None:
+        _dev_check(y, ev)
     x_hat = torch.empty((B, Ns, n_ds * n_sc, 2), dtype=torch.float32, device=dev)
     no_eff = torch.empty((B, Ns, n_ds * n_sc), dtype=torch.float32, device=dev)
-    no_dev = no.contiguous() if no_mode != 0 else None
+    if no_mode not in (0, 1, 2):
+        raise RuntimeError(f"no_mode must be 0, 1 or 2, got {no_mode}")
+    no_dev = None
+    if no_mode != 0:
+        _dev_check(y, no)
+        no_dev = _f32("no", no, B) if no_mode == 1 else _f32("no", no, B, Nr)
     with torch.cuda.device(dev):
         rc = _cabi.lib().cet_lmmse_grid(_ptr(y), _ptr(h_hat), _ptr(ev), no_mode, ctypes.c_float(no_scalar),
                                         _ptr(no_dev), _ptr(data_sym), _ptr(eff_sc), _ptr(x_hat),

@@ -22,7 +22,8 @@ extern "C" {
 
 enum {
   CET_OK = 0,
-  CET_ERR_INVALID_ARG = 1, /* null pointer, negative size, bad enum value                */
+  CET_ERR_INVALID_ARG = 1, /* null pointer, negative size, bad enum value, or a handle used
+                              while another HIP device than the one it was created on is current */
   CET_ERR_UNSUPPORTED = 2, /* well-formed request outside what the kernels are built for */
   CET_ERR_HIP = 3,         /* a HIP runtime call failed; see cet_last_hip_error()         */
   CET_ERR_ALLOC = 4,       /* host or device allocation failed                           */
@@ -102,6 +103,14 @@ size_t cet_informer_attn_size(cet_handle h, int B);
  *   attn  NULL, or cet_informer_attn_size(h,B) floats (what output_attention=True returns). */
 int cet_informer_forward(cet_handle h, const float* x_enc, const float* x_dec, float* out,
                          float* attn, int B, void* stream);
+
+/* Pins the launch shape of the Transformer kernel for later forwards of this handle (tests and
+ * timing; the default picks by batch size). kernel: 0 by batch size, 1 one wave per sequence,
+ * 2 workgroups of 8 sequences with the weights staged in LDS; pack: 1 / 0 two sequences per tile
+ * in the short encoder stages of the workgroup kernel, or not; -1 leaves a setting as it is.
+ * Not to be called while a forward of the same handle runs on another thread. No counterpart in
+ * the reference (PyTorch picks its kernels internally). */
+int cet_informer_select(cet_handle h, int kernel, int pack);
 
 /* Debug variant: additionally copies the activations after every stage into `taps`
  * (device, cet_informer_taps_size(h,B) floats; layout [stage][B][rows_of_stage][64]; features

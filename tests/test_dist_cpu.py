@@ -1,5 +1,8 @@
-"""The multi-rank reduction of the NMSE/BER partial sums, on CPU with gloo (world size 2)."""
+"""The multi-rank reduction of the NMSE/BER partial sums, on CPU with gloo (world size 2), and
+bench.py's own launcher."""
+import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -78,3 +81,30 @@ def test_two_rank_e2e_reduce():
     assert abs(res["ber_perfect_csi"] - 2.0 / 2000.0) < 1e-15
     want = 10 * np.log10(np.array([3.0 / 20.0, 4.0 / 41.0, 6.0 / 60.0]))
     assert np.allclose(res["nmse_db"], want, rtol=1e-12)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (here on the CPU:
+    --workload selftest runs the launcher, the rendezvous and the all-reduce over gloo) and rank 0
+    prints one JSON line for the whole job; a request that cannot be served exits non-zero."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "selftest"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16
+    assert out["all_reduce_matches_single_process"] is True
+    # under a launcher (WORLD_SIZE set) the same script is one rank and does not start others
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "selftest"],
+                        env=env1, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+    import torch
+    if torch.cuda.device_count() < 2:  # more ranks than GPUs: refused before anything starts
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                            capture_output=True, text=True, timeout=300)
+        assert r2.returncode != 0 and "GPU(s) visible" in r2.stderr

@@ -152,6 +152,18 @@ def test_shipped_hpc_checkpoints(name):
     assert np.abs(attns[0][0].cpu().numpy() - v[f"{name}/attn_0"]).max() < TOL_ATTN
 
 
+@pytest.mark.parametrize("name,cls", [("e2e_L5", "InformerStack_e2e"), ("V30", "InformerStack"), ("V60", "InformerStack")])
+def test_more_shipped_checkpoints(name, cls):
+    """prediciton_code/checkpoints/checkpoints_30-60_L5/informerstack_e2e_.../checkpoint.pth and
+    HPC/TrainedTransformers/best_model_params_V30.pt / _V60.pt with their stored key names, against
+    the imported reference's outputs (tests/golden/make_golden_shipped.py)."""
+    v = load_npz("informer_more.npz")
+    m = build(cls, DEFAULT_ARGS, sub_dict(v, f"{name}/sd")).cuda()
+    pred, attns = m(torch.from_numpy(v[f"{name}/x_enc"]).cuda(), torch.from_numpy(v[f"{name}/x_dec"]).cuda())
+    assert np.abs(pred.cpu().numpy() - v[f"{name}/pred"]).max() < TOL_PRED
+    assert np.abs(attns[0][0].cpu().numpy() - v[f"{name}/attn_0"]).max() < TOL_ATTN
+
+
 def test_e2e_class_is_the_same_wiring():
     """InformerStack_e2e (LocalSimulations/models/model.py:84-158) differs from InformerStack in
     its training target only: same state_dict keys, same outputs."""

@@ -175,16 +175,15 @@ def test_ls_estimator_nearest_neighbour(oracle):
 @pytest.mark.parametrize("N,h_share", [(14 * 300, 14), (14 * 300 - 5, 14), (4099, 3), (1000, 1000),
                                        (77, 2000), (64, 1)])
 @pytest.mark.parametrize("kernel", ["shared_factorisation", "gather"])
-def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, kernel, oracle, monkeypatch):
+def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, kernel, oracle):
     """One channel matrix held over h_share consecutive resource elements (a predicted slot):
     the block-fading entry points must return, bit for bit, what the per-element entry points
     return on the expanded H — ragged last block, ragged last tile, every noise mode, the fused
     demapper — and the float64 checker's values within the usual tolerance. Two kernels serve
     the entry points: one factorises each matrix once and applies it to the block's symbols
-    (scalar noise), the other is the per-element kernel gathering its matrix (other noise
-    modes; CET_LMMSE_BLOCK=gather selects it for scalar noise too)."""
-    if kernel == "gather":
-        monkeypatch.setenv("CET_LMMSE_BLOCK", "gather")
+    (scalar noise), the other is the per-element kernel gathering its matrix (the other noise
+    modes; a per-element noise array that holds one value everywhere sends the scalar case
+    through it too, and must reproduce the scalar entry point's bits)."""
     nb = -(-N // h_share)
     y, _, _ = synth.lmmse_problem(N, Nr, Ns, 0.1, seed=N + Nr + h_share)
     _, Hb, _ = synth.lmmse_problem(nb, Nr, Ns, 0.1, seed=7 * N + Ns)
@@ -198,9 +197,12 @@ def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, kernel, oracle
         x1, ne1 = cet.lmmse(yt, Hbt, no, h_share=h_share)
         assert torch.equal(torch.view_as_real(x0), torch.view_as_real(x1)) and torch.equal(ne0, ne1)
     want_x, want_ne = oracle.lmmse(y, H, 0.1)
-    x1, ne1 = cet.lmmse(yt, Hbt, 0.1, h_share=h_share)
+    no_arg = 0.1 if kernel == "shared_factorisation" else torch.full((N,), 0.1, device="cuda")
+    x1, ne1 = cet.lmmse(yt, Hbt, no_arg, h_share=h_share)
     assert close(x1.cpu().numpy(), want_x) and close(ne1.cpu().numpy(), want_ne)
-    assert torch.equal(cet.lmmse_llr(yt, Ht, 0.1), cet.lmmse_llr(yt, Hbt, 0.1, h_share=h_share))
+    x0, ne0 = cet.lmmse(yt, Ht, 0.1)
+    assert torch.equal(torch.view_as_real(x0), torch.view_as_real(x1)) and torch.equal(ne0, ne1)
+    assert torch.equal(cet.lmmse_llr(yt, Ht, 0.1), cet.lmmse_llr(yt, Hbt, no_arg, h_share=h_share))
     with pytest.raises(RuntimeError):
         cet.lmmse(yt, Hbt[:-1] if nb > 1 else Ht[:0], 0.1, h_share=h_share)
 

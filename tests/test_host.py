@@ -128,20 +128,29 @@ def test_antenna_grouping_round_trip():
         e2e.group_antennas(torch.zeros(1, 2, 6, 4))
 
 
-@pytest.mark.parametrize("name", sorted(RNN_CASES))
-def test_train_data_is_the_teacher_forced_pass(name, oracle):
-    """`train_data` (stock torch modules, autograd) against the checker: its output at step L - 1
-    is the first prediction of a rollout over the first L inputs."""
-    cls, kind, F, I, H, layers = RNN_CASES[name]
-    m = getattr(cet, cls)(F, I, H, layers)
-    sd = sub_dict(load_npz("rnn_ckpt.npz"), name)
-    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
-    x = torch.randn(3, 9, F, generator=torch.Generator().manual_seed(1))
-    out = m.train_data(x, "cpu")
-    assert out.shape == (3, 9, F) and out.requires_grad
-    blob = blobs.pack_rnn(sd, kind, F, I, H, layers)
-    for L in (1, 4, 9):
-        want = oracle.rnn_rollout(kind, F, I, H, layers, blob, x[:, :L].numpy().copy(), 1)
-        assert np.abs(out[:, L - 1].detach().numpy() - want[:, 0]).max() < 2e-5
-    out.square().mean().backward()
-    assert all(p.grad is not None for p in m.parameters())
+def test_copies_of_a_module_do_not_share_library_handles():
+    """copy.copy, copy.deepcopy, pickling and DataParallel's replicate must start with an empty
+    handle cache: a shared cache would have every copy free the original's handles when it is
+    collected (HPC/python/Evaluate.py:74 wraps the model in torch.nn.DataParallel)."""
+    import copy
+    import pickle
+    for m in (cet.InformerStack(*DEFAULT_ARGS).eval(), cet.GRU(16, 16, 256, 2).eval()):
+        m._handles[0] = (m._weights_version, 0xDEAD0, None)  # stands for a live library handle
+        try:
+            copies = [copy.copy(m), copy.deepcopy(m), pickle.loads(pickle.dumps(m)),
+                      m._replicate_for_data_parallel()]
+            for c in copies:
+                assert c._handles == {} and c._handles is not m._handles
+                assert set(c.state_dict().keys()) == set(m.state_dict().keys())
+            assert m._handles[0][1] == 0xDEAD0
+            # the shallow copies share the parameters, the deep ones own theirs
+            p0 = next(m.parameters())
+            assert next(copies[0].parameters()) is p0 and next(copies[1].parameters()) is not p0
+        finally:
+            m._handles.clear()  # nothing real to free
+        del copies
+
+
+def test_train_data_is_not_part_of_the_inference_path():
+    with pytest.raises(NotImplementedError, match="training"):
+        cet.GRU(16, 16, 256, 2).train_data(torch.zeros(2, 5, 16), "cpu")

@@ -142,3 +142,65 @@ def test_checker_on_shipped_hpc_checkpoints(name, oracle):
                                             want_attn=True, want_taps=True)
     assert np.abs(pred - v[f"{name}/pred"]).max() < 5e-6
     assert np.abs(attn[0] - v[f"{name}/attn_0"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("name", ["e2e_L5", "V30", "V60"])
+def test_checker_on_more_shipped_transformer_checkpoints(name, oracle):
+    """prediciton_code/checkpoints/checkpoints_30-60_L5/informerstack_e2e_.../checkpoint.pth,
+    HPC/TrainedTransformers/best_model_params_V30.pt and best_model_params_V60.pt, keys as stored,
+    on sequences of the reference's CR_data_30 / _60 (tests/golden/make_golden_shipped.py)."""
+    v = load_npz("informer_more.npz")
+    cfg = cfg_from_args(DEFAULT_ARGS, True)
+    blob = blobs.pack_informer(sub_dict(v, f"{name}/sd"), cfg)
+    pred, attn, _ = oracle.informer_forward(cfg, blob, v[f"{name}/x_enc"], v[f"{name}/x_dec"], want_attn=True)
+    assert np.abs(pred - v[f"{name}/pred"]).max() < TOL
+    assert np.abs(attn[0] - v[f"{name}/attn_0"]).max() < TOL
+
+
+@pytest.mark.parametrize("cell,kind", [("GRU", 1), ("LSTM", 2), ("RNN", 0)])
+@pytest.mark.parametrize("tag", ["fixed_direction", "best"])
+def test_checker_on_more_shipped_recurrent_checkpoints(cell, kind, tag, oracle):
+    """HPC/TrainedTransformers/{GRU,LSTM,RNN}_CDLBFixedDirection_..._uplink.pt and
+    {GRU,LSTM,RNN}_best_model_params_V30_uplink.pt: rollouts at pred_len 5 and 25."""
+    v = load_npz("rnn_more.npz")
+    blob = blobs.pack_rnn(sub_dict(v, f"{cell}_{tag}/sd"), kind, 16, 16, 256, 2)
+    for P in (5, 25):
+        want = v[f"{cell}_{tag}/pred{P}"]
+        out = oracle.rnn_rollout(kind, 16, 16, 256, 2, blob, v["x"], P)
+        assert np.abs(out - want).max() < 1e-5 * max(1.0, float(np.abs(want).max()))
+
+
+def nmse_db_per_slot(pred, truth):
+    return 10 * np.log10(((truth - pred) ** 2).sum((0, 2)) / (truth ** 2).sum((0, 2)))
+
+
+@pytest.mark.parametrize("cell,kind", [("GRU", 1), ("LSTM", 2), ("RNN", 0)])
+def test_checker_nmse_of_recurrent_predictors_on_stored_sequences(cell, kind, oracle):
+    """All 192 stored CDL-B sequences through the recurrent checkpoints trained on them
+    (checkpoints_30-60_L5) and through the HPC ones: outputs and per-slot NMSE (against slots
+    25..29 of CR_data_*) of the checker equal the imported reference's; tolerance 0.05 dB."""
+    v = load_npz("rnn_cr.npz")
+    ck = load_npz("rnn_ckpt.npz")
+    for name, sd in ((f"{cell}_L5", sub_dict(v, f"{cell}_L5/sd")), (cell, sub_dict(ck, cell))):
+        blob = blobs.pack_rnn(sd, kind, 16, 16, 256, 2)
+        out = oracle.rnn_rollout(kind, 16, 16, 256, 2, blob, v["x"], 5)
+        want = v[f"{name}/pred5"]
+        assert np.abs(out - want).max() < 1e-5 * max(1.0, float(np.abs(want).max()))
+        assert np.abs(nmse_db_per_slot(out, v["truth"]) - nmse_db_per_slot(want, v["truth"])).max() < 0.05
+
+
+def test_checker_on_the_12_head_35_slot_checkpoint(oracle):
+    """HPC/TrainedTransformers/InformerStack_5x_d_model64_n_heads12_..._seq_len35_label_len20_
+    pred_len5_..._uplink.pt: 12 heads of 64 // 12 = 5 features (60-wide projections,
+    models/attn.py:126-133), 35-slot history, 25-row decoder input."""
+    v = load_npz("informer_h12.npz")
+    cfg = blobs.make_informer_cfg(16, 16, 16, 35, 20, 5, 64, 12, 4, 3, 64, True, True, "gelu")
+    blob = blobs.pack_informer(sub_dict(v, "h12/sd"), cfg)
+    assert blob.size == blobs.informer_blob_len(cfg)
+    pred, attn, taps = oracle.informer_forward(cfg, blob, v["h12/x_enc"], v["h12/x_dec"], True, True)
+    assert np.abs(pred - v["h12/pred"]).max() < TOL
+    for i, t in enumerate(taps):
+        assert np.abs(t - v[f"h12/tap_{i}"]).max() < 2e-5, f"stage {i}"
+    for i, a in enumerate(attn):
+        assert a.shape == v[f"h12/attn_{i}"].shape
+        assert np.abs(a - v[f"h12/attn_{i}"]).max() < TOL, f"attention map {i}"
