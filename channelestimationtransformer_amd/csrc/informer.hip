@@ -208,6 +208,10 @@ struct Stage {
   unsigned lds;         // LDS byte address of buf
   int next, total;      // next block to request; number of blocks
   int wave, lane;
+  int pub;              // staging barriers passed = blocks published to this wave
+  int use;              // next block this wave consumes
+  bool lag;             // this wave runs one staging barrier ahead of its consumption (see stage_lag)
+  int dma_first, dma_step;  // this wave requests pieces dma_first, dma_first + dma_step, ... of a block
 };
 DEV unsigned lds_address(const void* p) {
   return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
@@ -224,26 +228,56 @@ DEV void dma16(const void* src, unsigned lds_addr_wave_uniform) {
       : "memory");
 }
 // Requests the next block into the buffer (next & 1): 18 wave instructions of 1 KiB, spread
-// over the 8 waves.
+// over the 8 waves (over waves 4..7 alone while those have nothing else to do, see stage_share).
 DEV void stage_request(Stage& st) {
   if (st.next >= st.total) return;
   const char* src = reinterpret_cast<const char*>(st.blocks + (size_t)st.next * WBLK) + 16 * st.lane;
   const unsigned dst = st.lds + (st.next & 1) * (WBLK * 4);
-  for (int i = st.wave; i < WBLK * 4 / 1024; i += WG_WAVES) dma16(src + i * 1024, dst + i * 1024);
+  for (int i = st.dma_first; i < WBLK * 4 / 1024; i += st.dma_step) dma16(src + i * 1024, dst + i * 1024);
   ++st.next;
 }
-// Returns block `next - 1` once it is complete in LDS for the whole workgroup, and requests its
-// successor. The barrier also tells that every wave is done with the block before, whose
-// buffer the new request overwrites.
-DEV const float* stage_acquire(Stage& st) {
+// Staging barrier number `pub` (all 8 waves pass the same sequence of them): every wave's share
+// of block `pub` has landed and every wave is done reading block `pub - 1`, whose buffer the
+// request for block `pub + 1` then overwrites. The wait also covers this wave's own LDS reads.
+DEV void stage_barrier(Stage& st) {
 #ifdef CET_EXP_NOBARRIER  // timing experiment: what the workgroup barrier costs (results invalid)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #else
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-  const float* cur = st.buf + ((st.next - 1) & 1) * WBLK;
+  __builtin_amdgcn_sched_barrier(0);  // nothing that follows is moved in front of the rendezvous
+  ++st.pub;
   stage_request(st);
-  return cur;
+}
+// The next block of the consumption order, once it is published to this wave.
+DEV const float* stage_acquire(Stage& st) {
+  if (st.pub <= st.use) stage_barrier(st);
+  return st.buf + (st.use++ & 1) * WBLK;
+}
+// Waves 4..7 of a workgroup share their SIMDs with waves 0..3. Left alone, both waves of a SIMD
+// would wait at the same barrier, read their weight fragments at the same time (8 x 16 KiB
+// through the LDS pipe) and only then start their MFMAs. In lag mode a wave passes the NEXT
+// staging barrier right after its fragment reads and before its MFMAs: its matrix and vector work
+// on block k then runs while the other wave of the SIMD waits for and reads block k + 1, and the
+// other way round. The count of barriers is the same for every wave; only their place in the
+// instruction stream differs. No barrier exists beyond the last block.
+DEV void stage_lag(Stage& st) {
+  if (st.lag && st.pub < st.total) stage_barrier(st);
+}
+// Who requests the pieces of a block: all 8 waves in turn, or (busy_low) waves 4..7 only.
+DEV void stage_share(Stage& st, bool busy_low) {
+  if (!busy_low) {
+    st.dma_first = st.wave;
+    st.dma_step = WG_WAVES;
+  } else {
+    st.dma_first = st.wave >= WG_WAVES / 2 ? st.wave - WG_WAVES / 2 : WBLK;  // WBLK: none
+    st.dma_step = WG_WAVES / 2;
+  }
+}
+// Brings every wave to the same number of passed staging barriers (one ahead of consumption)
+// before a barrier of another kind; a wave in lag mode is there already.
+DEV void stage_align(Stage& st) {
+  while (st.pub <= st.use && st.pub < st.total) stage_barrier(st);
 }
 
 // out^T[rt][mo] = W[64 x 64] * in^T  (+ bias). W row-major [out][in], bias[out].
@@ -306,8 +340,12 @@ DEV void wload_lds(WFrag& f, const float* blk, const Lane ln, NormParams* norm =
 template <bool WG>
 DEV void next_weights(WFrag& f, Stage& st, const float* __restrict__ W, const Lane ln,
                       NormParams* norm = nullptr, const float* __restrict__ norm_w = nullptr) {
-  if (WG) wload_lds(f, stage_acquire(st), ln, norm);
-  else wload(f, W, ln, norm, norm_w);
+  if (WG) {
+    wload_lds(f, stage_acquire(st), ln, norm);
+    stage_lag(st);
+  } else {
+    wload(f, W, ln, norm, norm_w);
+  }
 }
 // out^T[rt][mo] = W * in^T + bias
 template <int RT>
@@ -425,10 +463,12 @@ DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const f32x4 (&
 // Heads are processed NP pairs at a time, each step for all of them before the next step:
 // scores (MFMA), softmax (VALU, cross-lane), P*V (MFMA). The steps of different heads are
 // independent, so their latencies overlap instead of forming one long dependent chain.
-// QREG: the queries are not in LDS but in registers (q, T layout). A lane's four features of
-// tile mt then serve directly as B operands, the keys are read as the matching 16-byte groups,
-// and the sum over a tile's 16 features is split into its two heads by zeroing the K operand
-// of the lane groups that hold the other head's features (4 MFMAs of k = 4 per head).
+// QREG: the queries are not in LDS but in registers (q, T layout), and the Q and K projections
+// were taken with row-permuted weights (qk_row() on the host) so that position 16 t + 4 g + i of
+// their outputs holds feature 16 t + 8 (i >> 1) + 2 g + (i & 1): register i of tile t then spans,
+// over the four lane groups g (the k index of the MFMA), features of ONE head, and a head's
+// scores are two MFMAs of k = 4 (registers 2 hh and 2 hh + 1) with the query registers as B
+// operands as they stand and the keys read as the matching 16-byte groups.
 // pack_L > 0 (single tiles only): the tile holds two sequences of pack_L <= 8 rows, at rows
 // 0.. and 8..; a query then only admits the keys of its own sequence, and amap / amap2 are the
 // maps of the first / second sequence (Lq = Lk = 16 for the row bookkeeping).
@@ -464,24 +504,21 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
 #pragma unroll
         for (int kt = 0; kt < RK; ++kt)
           kf[pi][kt] = ld4(Kb + (16 * kt + ln.c) * LDW + 16 * (hp0 + pi) + 4 * ln.g);
-      const bool low = ln.g < 2;  // this lane's features belong to the first head of a pair
+      // registers 2 hh and 2 hh + 1 of a tile hold, over the four lane groups, the 8 features
+      // of head hh of the pair (the staged Q / K weights are row-permuted for this, qk_row())
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-          for (int kt = 0; kt < RK; ++kt) {
-            f32x4 km;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) km[i] = ((hh == 0) == low) ? kf[pi][kt][i] : 0.f;
+          for (int kt = 0; kt < RK; ++kt)
 #pragma unroll
             for (int qt = 0; qt < RQ; ++qt) {
               f32x4 sc = zero4();
-#pragma unroll
-              for (int i = 0; i < 4; ++i) sc = mfma(km[i], q[qt][hp0 + pi][i], sc);
+              sc = mfma(kf[pi][kt][2 * hh], q[qt][hp0 + pi][2 * hh], sc);
+              sc = mfma(kf[pi][kt][2 * hh + 1], q[qt][hp0 + pi][2 * hh + 1], sc);
               p[pi][hh][kt][qt] = sc;
             }
-          }
     } else {
       float2 kf[NP][2][RK], qf[NP][2][RQ];
 #pragma unroll
@@ -782,6 +819,7 @@ DEV int distil(const float* __restrict__ w, Stage& st, float* smem, int R, const
     for (int j = 0; j < 3; ++j) {
       WFrag A;
       wload_lds(A, stage_acquire(st), ln, j == 0 ? &ab : nullptr);
+      stage_lag(st);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         int t = 16 * rt + ln.c;
@@ -1182,7 +1220,7 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   float* smem = WG ? smem_all + 2 * WBLK + wave * a.wave_lds_floats : smem_all;
 #ifdef CET_PROF
   int prof_idx = 0;
-  const int prof_stride = a.B >= PROF_SAMPLES ? a.B / PROF_SAMPLES : 1;
+  const int prof_stride = a.B >= PROF_SAMPLES ? (a.B / PROF_SAMPLES) | 4 : 1;  // waves 0 and 4 in turn
   const int prof_slot = seq / prof_stride;
   const bool prof_on = valid && seq % prof_stride == 0 && prof_slot < PROF_SAMPLES;
   Lane ln{lane & 15, lane >> 4, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)), a.ln_inv_n, a.ln_pad,
@@ -1197,7 +1235,8 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
 #ifdef CET_EXP
   ln.ablate = a.ablate;
 #endif
-  Stage st{a.wblk, smem_all, WG ? lds_address(smem_all) : 0u, 0, WG ? a.n_blk : 0, wave, lane};
+  Stage st{a.wblk, smem_all, WG ? lds_address(smem_all) : 0u, 0, WG ? a.n_blk : 0, wave, lane, 0, 0,
+           WG && wave >= WG_WAVES / 2, wave, WG_WAVES};
   if (WG) stage_request(st);  // block 0 travels while the embedding is computed
 
   // Rows the padded 16-row tiles may touch must hold finite numbers from the start.
@@ -1238,6 +1277,9 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   if (WG && i < a.n_ops) {
     // hand the partner's rows to the primary (see "two sequences in one tile")
     const int L0 = a.ops[i].L;
+    stage_align(st);
+    st.lag = false;  // the packed steps are computed by waves 0..3 alone,
+    stage_share(st, true);  // and waves 4..7, idle meanwhile, request the weight blocks
     if (wave >= WG_WAVES / 2) {
       wave_sync();
       store_rows<1>(smem, ln, x, L0);
@@ -1258,6 +1300,8 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
     }
   }
   tap<RM>(cu.taps, a.B, b, a.mem_rows, ln, mem);
+  st.lag = WG && wave >= WG_WAVES / 2;
+  stage_share(st, false);
 
   // ---- decoder ---------------------------------------------------------------------
   {
@@ -1398,6 +1442,13 @@ size_t informer_blob_size(const cet_informer_cfg* c) {
   return n;
 }
 
+// Output position p of a staged query / key projection holds feature qk_row(p): inside every
+// 16-feature tile, position 4 g + i <- feature 8 (i >> 1) + 2 g + (i & 1).
+static int qk_row(int p) {
+  const int t = p >> 4, g = (p >> 2) & 3, i = p & 3;
+  return 16 * t + 8 * (i >> 1) + 2 * g + (i & 1);
+}
+
 // [out][in][3] (PyTorch Conv1d) -> [3][out][in]
 static void conv_taps_major(const float* src, int cout, int cin, std::vector<float>& dst) {
   for (int j = 0; j < 3; ++j)
@@ -1523,12 +1574,17 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   }
   // Staged blocks of the workgroup kernel, in consumption order: every Linear(64,64) as
   // W[64][LDW] | bias | gamma | beta (the LayerNorm that follows it, if any) | zero padding.
+  // qk: the block is a query or key projection, whose output rows the workgroup kernel wants in
+  // the order of qk_row() (see attention<.., QREG>).
   std::vector<float> blk;
-  auto add_block = [&](const float* lin, const float* norm) {
+  auto add_block = [&](const float* lin, const float* norm, bool qk = false) {
     const size_t base = blk.size();
     blk.resize(base + WBLK, 0.f);
-    for (int r = 0; r < DM; ++r) std::copy(lin + (size_t)r * DM, lin + (size_t)(r + 1) * DM, blk.begin() + base + (size_t)r * LDW);
-    std::copy(lin + D * D, lin + D * D + D, blk.begin() + base + WBLK_BIAS);
+    for (int r = 0; r < DM; ++r) {
+      const int src = qk ? qk_row(r) : r;
+      std::copy(lin + (size_t)src * DM, lin + (size_t)(src + 1) * DM, blk.begin() + base + (size_t)r * LDW);
+      blk[base + WBLK_BIAS + r] = lin[D * D + src];
+    }
     if (norm) std::copy(norm, norm + 2 * D, blk.begin() + base + WBLK_NORM);
   };
   const size_t lin_sz = D * D + D;
@@ -1542,7 +1598,7 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
       {
         const float* lw = layers + layer_sz * l;       // q k v o conv1 conv2 norm1 norm2
         const float* norms = lw + 6 * lin_sz;
-        for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr);
+        for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr, k < 2);
         add_block(lw + 3 * lin_sz, norms);
         add_block(lw + 4 * lin_sz, nullptr);
         add_block(lw + 5 * lin_sz, norms + 2 * D);
@@ -1581,9 +1637,9 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   for (int l = 0; l < c->d_layers; ++l) {
     const float* lw = p;  // self q k v o | cross q k v o | conv1 conv2 | norm1 norm2 norm3
     const float* norms = lw + 10 * lin_sz;
-    for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr);
+    for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr, k < 2);
     add_block(lw + 3 * lin_sz, norms);
-    for (int k = 4; k < 7; ++k) add_block(lw + k * lin_sz, nullptr);
+    for (int k = 4; k < 7; ++k) add_block(lw + k * lin_sz, nullptr, k < 6);
     add_block(lw + 7 * lin_sz, norms + 2 * D);
     add_block(lw + 8 * lin_sz, nullptr);
     add_block(lw + 9 * lin_sz, norms + 4 * D);
@@ -1789,6 +1845,18 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
       tot += (double)((t[n - 1] >> 4) - (t[0] >> 4));
       if (waves == 1 || (double)(t[0] >> 4) < t0min) t0min = (double)(t[0] >> 4);
       if ((double)(t[n - 1] >> 4) > t1max) t1max = (double)(t[n - 1] >> 4);
+    }
+    if (const char* dump = getenv("CET_PROF_DUMP")) {  // raw stamp traces, one line per sampled wave
+      if (FILE* f = fopen(dump, "a")) {
+        for (int s = 0; s < PROF_SAMPLES; ++s) {
+          const unsigned long long* t = h + (size_t)s * PROF_MAXM;
+          if (!t[0]) continue;
+          fprintf(f, "B=%d wave", B);
+          for (int n = 0; n < PROF_MAXM && t[n]; ++n) fprintf(f, " %llu:%d", (t[n] >> 4) - (t[0] >> 4), (int)(t[n] & 15));
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
     }
     if (waves) {
       fprintf(stderr, "[cet prof] %d sampled waves, clocks per wave:", waves);
