@@ -40,9 +40,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // for 4-byte aligned vector stores
 
 constexpr int DM = 64;    // d_model
-constexpr int NHEAD = 8;  // heads (head dim 8)
+constexpr int HDIM = 8;   // features per head as the kernels lay them out (d_keys <= 8, zero padded)
 constexpr int LDW = 68;   // LDS row stride in floats (64 + 4: conflict-free fragment reads)
-constexpr int MAXROWS = 32;
+constexpr int MAXT = 3;   // row tiles of 16 an activation can span (sequences of up to 48 rows)
+constexpr int MAXQ = 6;   // 16-feature tiles of the widest activation (Q / K / V of 12 heads)
+constexpr int MAXROWS = 16 * MAXT;
+// An activation in T layout: [row tile][feature tile]. Only the tiles a kernel instantiation
+// touches ever exist (the arrays are fully scalarised), so the bounds cost nothing.
+typedef f32x4 Act[MAXT][MAXQ];
+// Heads come in pairs (one 16-feature tile each): NHP = 4 serves up to 8 heads, NHP = 6 up to 12.
+// Row stride of the Q / K / V rows in LDS for NHP head pairs.
+template <int NHP> constexpr int ldq() { return 16 * NHP + 4; }
 
 struct Dims {
   int enc_in, dec_in, c_out, seq_len, label_len, pred_len;
@@ -75,7 +83,7 @@ struct KArgs {
   int n_enc, distil, activation, d_layers;
   int enc_layers[8];
   int region_rows;  // rows of each of the three LDS regions (Q | K | V)
-  int n_ops, n_ops2;  // encoder steps; the first n_ops2 of them touch more than 16 rows
+  int n_ops, n_ops2, n_ops3;  // encoder steps; the first n_ops2 touch > 16 rows, the first n_ops3 > 32
   int mem_rows;
   Op ops[MAX_OPS];
 #ifdef CET_EXP
@@ -87,6 +95,7 @@ struct KArgs {
   int n_pack0;          // workgroup kernel: first step that runs on packed tiles (n_ops: none)
   float ln_inv_n, ln_pad;  // LayerNorm: 1 / d_model and the number of zero-padded features
   float attn_c;            // log2(e) / sqrt(d_keys)
+  int n_heads;             // heads of the model
   unsigned long long* prof;  // profiling build only
 };
 
@@ -151,6 +160,7 @@ struct Lane {
   unsigned wo;  // c * 64 + 4 * g : this lane's offset inside a 16-row block of a [.][64] matrix
   float inv_n, pad_n;  // LayerNorm over the real features: 1 / d_model, 64 - d_model
   float attn_c;        // softmax scale times log2(e)
+  int n_heads;         // heads of the model (attention maps exist for these only)
 #ifdef CET_EXP
   int ablate;  // experiment build only: mask of the parts to skip
 #endif
@@ -300,19 +310,22 @@ DEV void load_norm(NormParams& n, const float* __restrict__ gamma_beta_, const L
 
 // Weight fragments of one 64x64 product (A operands of all 64 MFMAs per row tile) + bias.
 struct WFrag {
-  f32x4 a[4][4], bv[4];
+  f32x4 a[MAXQ][MAXQ], bv[MAXQ];  // [output tile][input tile]
 };
 // Requests the fragments of W[64][64] (row-major) and bias[64]. The sched_barrier pins the
 // requests where they are written: the kernel's layer schedules issue them one product ahead
 // of their use, which the register-bound compiler would otherwise undo.
+template <int MO = 4, int KI = 4>  // W[16 MO][16 KI] row-major | bias[16 MO]
 DEV void wload(WFrag& f, const float* __restrict__ W, const Lane ln, NormParams* norm = nullptr,
                const float* __restrict__ norm_w = nullptr) {
-  const gptr bias = uniform(W + DM * DM);
+  constexpr int IN = 16 * KI;
+  const gptr bias = uniform(W + 16 * MO * IN);
+  const unsigned wo = KI == 4 ? ln.wo : (unsigned)(ln.c * IN + 4 * ln.g);
 #pragma unroll
-  for (int mo = 0; mo < 4; ++mo) {
-    const gptr Wm = uniform(W + 16 * mo * DM);
+  for (int mo = 0; mo < MO; ++mo) {
+    const gptr Wm = uniform(W + 16 * mo * IN);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) f.a[mo][mi] = ld4(Wm + ln.wo + 16 * mi);
+    for (int mi = 0; mi < KI; ++mi) f.a[mo][mi] = ld4(Wm + wo + 16 * mi);
     f.bv[mo] = ld4(bias + 16 * mo + 4 * ln.g);
   }
   if (norm) load_norm(*norm, norm_w, ln);
@@ -337,26 +350,27 @@ DEV void wload_lds(WFrag& f, const float* blk, const Lane ln, NormParams* norm =
 }
 // Fragments of the next Linear of the layer: from global memory (one-wave kernel) or from the
 // next staged block (workgroup kernel; the global pointers are then unused).
-template <bool WG>
+template <bool WG, int MO = 4, int KI = 4>
 DEV void next_weights(WFrag& f, Stage& st, const float* __restrict__ W, const Lane ln,
                       NormParams* norm = nullptr, const float* __restrict__ norm_w = nullptr) {
   if (WG) {
+    static_assert(!WG || (MO == 4 && KI == 4), "staged blocks are 64 x 64");
     wload_lds(f, stage_acquire(st), ln, norm);
     stage_lag(st);
   } else {
-    wload(f, W, ln, norm, norm_w);
+    wload<MO, KI>(f, W, ln, norm, norm_w);
   }
 }
 // out^T[rt][mo] = W * in^T + bias
-template <int RT>
-DEV void wmul(const WFrag& f, const f32x4 (&in)[2][4], f32x4 (&out)[2][4]) {
+template <int RT, int MO = 4, int KI = 4>
+DEV void wmul(const WFrag& f, const Act& in, Act& out) {
 #pragma unroll
-  for (int mo = 0; mo < 4; ++mo) {
+  for (int mo = 0; mo < MO; ++mo) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       f32x4 acc = f.bv[mo];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < KI; ++mi)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc = mfma(f.a[mo][mi][i], in[rt][mi][i], acc);
       out[rt][mo] = acc;
@@ -366,20 +380,20 @@ DEV void wmul(const WFrag& f, const f32x4 (&in)[2][4], f32x4 (&out)[2][4]) {
 
 // Rows [0, nrows) of the tiles go to LDS; rows of the padded tiles beyond that are dropped
 // (the regions are sized to the sequence, not to whole tiles).
-template <int RT>
-DEV void store_rows(float* buf, const Lane ln, const f32x4 (&v)[2][4], int nrows) {
+template <int RT, int NT = 4, int LD = LDW>  // NT feature tiles per row, row stride LD floats
+DEV void store_rows(float* buf, const Lane ln, const Act& v, int nrows) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     if (16 * rt + ln.c < nrows) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) st4(buf + (16 * rt + ln.c) * LDW + 16 * m + 4 * ln.g, v[rt][m]);
+      for (int m = 0; m < NT; ++m) st4(buf + (16 * rt + ln.c) * LD + 16 * m + 4 * ln.g, v[rt][m]);
     }
   }
 }
 
 // torch.nn.LayerNorm(64), eps 1e-5, over the feature axis (in-lane 16 values + lane groups).
 template <int RT>
-DEV void layer_norm(f32x4 (&x)[2][4], const NormParams& n, const Lane ln) {
+DEV void layer_norm(Act& x, const NormParams& n, const Lane ln) {
   if (ABLATED(ln, 16)) return;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -404,7 +418,7 @@ DEV void layer_norm(f32x4 (&x)[2][4], const NormParams& n, const Lane ln) {
   }
 }
 template <int RT>
-DEV void layer_norm(f32x4 (&x)[2][4], const float* __restrict__ gamma,
+DEV void layer_norm(Act& x, const float* __restrict__ gamma,
                     const float* __restrict__ beta, const Lane ln) {
   (void)beta;  // stored right behind gamma
   NormParams n;
@@ -435,7 +449,7 @@ DEV f32x4 act(f32x4 v, int activation) {
 }
 
 template <int RT>
-DEV void add_into(f32x4 (&x)[2][4], const f32x4 (&y)[2][4]) {
+DEV void add_into(Act& x, const Act& y) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -444,7 +458,7 @@ DEV void add_into(f32x4 (&x)[2][4], const f32x4 (&y)[2][4]) {
 
 // Copies the first `rows` rows to the debug buffer, stage-major [stage][B][rows][64].
 template <int RT>
-DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const f32x4 (&x)[2][4]) {
+DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const Act& x) {
   if (!taps) return;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -472,11 +486,13 @@ DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const f32x4 (&
 // pack_L > 0 (single tiles only): the tile holds two sequences of pack_L <= 8 rows, at rows
 // 0.. and 8..; a query then only admits the keys of its own sequence, and amap / amap2 are the
 // maps of the first / second sequence (Lq = Lk = 16 for the row bookkeeping).
-template <int RQ, int RK, bool QREG>
-DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, const float* Vb, int Lq,
-                   int Lk, bool causal, const Lane ln, f32x4 (&ctx)[2][4], float* amap,
+template <int RQ, int RK, bool QREG, int NHP = 4>
+DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* Vb, int Lq,
+                   int Lk, bool causal, const Lane ln, Act& ctx, float* amap,
                    int pack_L = 0, float* amap2 = nullptr) {
-  constexpr int NP = (RQ * RK == 1) ? 4 : (RQ * RK == 2 ? 2 : 1);  // head pairs per group
+  constexpr int LDQ = ldq<NHP>();
+  // head pairs per group (a divisor of NHP)
+  constexpr int NP = (RQ * RK == 1) ? (NHP % 4 == 0 ? 4 : 2) : (RQ * RK == 2 ? 2 : 1);
   // softmax(scale * s) is evaluated as 2^(c s + bias - max) / sum with c = scale * log2(e);
   // bias is 0 for admitted keys and -inf for padded or (causal) future ones.
   const float c = ln.attn_c;  // float(1 / sqrt(d_keys)) * log2 e
@@ -494,7 +510,7 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
         bias[kt][qt][i] = ok ? 0.f : -INFINITY;
       }
 #pragma unroll
-  for (int hp0 = 0; hp0 < 4; hp0 += NP) {
+  for (int hp0 = 0; hp0 < NHP; hp0 += NP) {
     f32x4 p[NP][2][RK][RQ];  // [pair][head of the pair][key tile][query tile]
     // ---- scores^T = K Q^T: lane (query 16*qt + c) holds keys 16*kt + 4*g + i ----
     if (QREG) {
@@ -503,7 +519,7 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
       for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
         for (int kt = 0; kt < RK; ++kt)
-          kf[pi][kt] = ld4(Kb + (16 * kt + ln.c) * LDW + 16 * (hp0 + pi) + 4 * ln.g);
+          kf[pi][kt] = ld4(Kb + (16 * kt + ln.c) * LDQ + 16 * (hp0 + pi) + 4 * ln.g);
       // registers 2 hh and 2 hh + 1 of a tile hold, over the four lane groups, the 8 features
       // of head hh of the pair (the staged Q / K weights are row-permuted for this, qk_row())
 #pragma unroll
@@ -528,10 +544,10 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
           const int col = 8 * (2 * (hp0 + pi) + hh) + 2 * ln.g;  // this lane's two head features
 #pragma unroll
           for (int kt = 0; kt < RK; ++kt)
-            kf[pi][hh][kt] = *reinterpret_cast<const float2*>(Kb + (16 * kt + ln.c) * LDW + col);
+            kf[pi][hh][kt] = *reinterpret_cast<const float2*>(Kb + (16 * kt + ln.c) * LDQ + col);
 #pragma unroll
           for (int qt = 0; qt < RQ; ++qt)
-            qf[pi][hh][qt] = *reinterpret_cast<const float2*>(Qb + (16 * qt + ln.c) * LDW + col);
+            qf[pi][hh][qt] = *reinterpret_cast<const float2*>(Qb + (16 * qt + ln.c) * LDQ + col);
         }
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi)
@@ -608,7 +624,7 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
             // rows of a map are at most 8 floats here: single stores
             float* mp = (ln.c >> 3) ? amap2 : amap;
             const int ql = ln.c & 7;
-            if (mp && ql < pack_L) {
+            if (mp && ql < pack_L && 2 * (hp0 + pi) + hh < ln.n_heads) {
               float* row = mp + ((size_t)(2 * (hp0 + pi) + hh) * pack_L + ql) * pack_L;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -616,7 +632,7 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
                 if (kl >= 0 && kl < pack_L) row[kl] = p[pi][hh][0][qt][i];
               }
             }
-          } else if (amap && query < Lq) {
+          } else if (amap && query < Lq && 2 * (hp0 + pi) + hh < ln.n_heads) {
             // a lane's four consecutive keys go out as one 16-byte store (rows of the map are
             // only 4-byte aligned; global memory takes unaligned vector stores), the ragged
             // end of a row as single floats
@@ -645,7 +661,7 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
         for (int i = 0; i < 4; ++i) {
           int vr = 16 * kt + 4 * ln.g + i;
           vr = vr < Lk ? vr : Lk - 1;  // padded keys carry probability 0; stay inside the region
-          vf[pi][kt][i] = Vb[vr * LDW + 16 * (hp0 + pi) + ln.c];
+          vf[pi][kt][i] = Vb[vr * LDQ + 16 * (hp0 + pi) + ln.c];
         }
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi) {
@@ -671,16 +687,17 @@ DEV void attention(const f32x4 (&q)[2][4], const float* Qb, const float* Kb, con
 }
 
 // Blob block sizes (floats), execution order.
-constexpr int SZ_ATTN = 4 * (DM * DM + DM);
-constexpr int SZ_FFN = 2 * (DM * DM + DM);
-
 constexpr int SZ_LIN = DM * DM + DM;  // one Linear(64,64): weight | bias
+constexpr int SZ_FFN = 2 * SZ_LIN;
+// Q / K / V projection 64 -> 16 NHP (weight | bias) and output projection 16 NHP -> 64
+template <int NHP> constexpr int sz_qkv() { return 16 * NHP * DM + 16 * NHP; }
+template <int NHP> constexpr int sz_attn() { return 3 * sz_qkv<NHP>() + DM * 16 * NHP + DM; }
 #ifndef CET_WPS
 #define CET_WPS 2  // waves per SIMD the register budget is set for
 #endif
 
 template <int RT>
-DEV void activate(f32x4 (&h)[2][4], int activation) {
+DEV void activate(Act& h, int activation) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -689,52 +706,54 @@ DEV void activate(f32x4 (&h)[2][4], int activation) {
 
 // LDS regions of a wave: one-wave kernel Q | K | V (R rows each), workgroup kernel K | V (the
 // queries stay in registers). A padded tile read may run into the next region (finite data).
-template <bool WG>
+template <bool WG, int NHP>
 DEV float* region_q(float* smem, int R) { return smem; }
-template <bool WG>
-DEV float* region_k(float* smem, int R) { return WG ? smem : smem + R * LDW; }
-template <bool WG>
-DEV float* region_v(float* smem, int R) { return WG ? smem + R * LDW : smem + 2 * R * LDW; }
+template <bool WG, int NHP>
+DEV float* region_k(float* smem, int R) { return WG ? smem : smem + R * ldq<NHP>(); }
+template <bool WG, int NHP>
+DEV float* region_v(float* smem, int R) { return WG ? smem + R * ldq<NHP>() : smem + 2 * R * ldq<NHP>(); }
 
 // The three projections of an attention layer: K and V go to LDS, Q to LDS (one-wave kernel)
 // or stays in registers (workgroup kernel).
-template <int RQ, int RK, bool WG>
+template <int RQ, int RK, bool WG, int NHP>
 DEV void project_qkv(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
-                     const f32x4 (&xq)[2][4], const f32x4 (&xkv)[2][4], int Lq, int Lk,
-                     f32x4 (&q)[2][4]) {
+                     const Act& xq, const Act& xkv, int Lq, int Lk,
+                     Act& q) {
+  constexpr int LDQ = ldq<NHP>();
   WFrag A;
-  f32x4 t[2][4];
+  Act t;
   wave_sync();  // earlier reads of the regions are issued
-  next_weights<WG>(A, st, w, ln);
-  wmul<RQ>(A, xq, q);
-  if (!WG) store_rows<RQ>(region_q<WG>(smem, R), ln, q, Lq);
-  next_weights<WG>(A, st, w + SZ_LIN, ln);
-  wmul<RK>(A, xkv, t);
-  store_rows<RK>(region_k<WG>(smem, R), ln, t, Lk);
-  next_weights<WG>(A, st, w + 2 * SZ_LIN, ln);
-  wmul<RK>(A, xkv, t);
-  store_rows<RK>(region_v<WG>(smem, R), ln, t, Lk);
+  next_weights<WG, NHP, 4>(A, st, w, ln);
+  wmul<RQ, NHP, 4>(A, xq, q);
+  if (!WG) store_rows<RQ, NHP, LDQ>(region_q<WG, NHP>(smem, R), ln, q, Lq);
+  next_weights<WG, NHP, 4>(A, st, w + sz_qkv<NHP>(), ln);
+  wmul<RK, NHP, 4>(A, xkv, t);
+  store_rows<RK, NHP, LDQ>(region_k<WG, NHP>(smem, R), ln, t, Lk);
+  next_weights<WG, NHP, 4>(A, st, w + 2 * sz_qkv<NHP>(), ln);
+  wmul<RK, NHP, 4>(A, xkv, t);
+  store_rows<RK, NHP, LDQ>(region_v<WG, NHP>(smem, R), ln, t, Lk);
   wave_sync();
   PROF_MARK(ln, P_QKV);
 }
 
 // EncoderLayer.forward (encoder.py:37-53) with AttentionLayer / FullAttention (attn.py).
 // Block: q,k,v,o Linear | conv1 | conv2 | norm1 g,b | norm2 g,b.
-constexpr int SZ_ENC_LAYER = SZ_ATTN + SZ_FFN + 4 * DM;
-template <int RT, bool WG>
+template <int NHP> constexpr int sz_enc_layer() { return sz_attn<NHP>() + SZ_FFN + 4 * DM; }
+template <int RT, bool WG, int NHP>
 DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
-                       int L, int activation, float* amap, f32x4 (&x)[2][4], int pack_L = 0,
+                       int L, int activation, float* amap, Act& x, int pack_L = 0,
                        float* amap2 = nullptr) {
+  constexpr int SZ_ATTN = sz_attn<NHP>();
   const float* nw = w + SZ_ATTN + SZ_FFN;
   WFrag A;
   NormParams n;
-  f32x4 t[2][4], y[2][4];
-  project_qkv<RT, RT, WG>(w, st, smem, R, ln, x, x, L, L, t);
-  attention<RT, RT, WG>(t, region_q<WG>(smem, R), region_k<WG>(smem, R), region_v<WG>(smem, R), L, L,
-                        false, ln, y, amap, pack_L, amap2);
+  Act t, y;
+  project_qkv<RT, RT, WG, NHP>(w, st, smem, R, ln, x, x, L, L, t);
+  attention<RT, RT, WG, NHP>(t, region_q<WG, NHP>(smem, R), region_k<WG, NHP>(smem, R),
+                             region_v<WG, NHP>(smem, R), L, L, false, ln, y, amap, pack_L, amap2);
   PROF_MARK(ln, P_ATTN);
-  next_weights<WG>(A, st, w + 3 * SZ_LIN, ln, &n, nw);  // output projection, norm1
-  wmul<RT>(A, y, t);
+  next_weights<WG, 4, NHP>(A, st, w + 3 * sz_qkv<NHP>(), ln, &n, nw);  // output projection, norm1
+  wmul<RT, 4, NHP>(A, y, t);
   PROF_MARK(ln, P_OPROJ);
   add_into<RT>(x, t);
   layer_norm<RT>(x, n, ln);
@@ -752,35 +771,36 @@ DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
 
 // DecoderLayer.forward (decoder.py:20-36).
 // Block: self q,k,v,o | cross q,k,v,o | conv1 | conv2 | norm1 | norm2 | norm3.
-constexpr int SZ_DEC_LAYER = 2 * SZ_ATTN + SZ_FFN + 6 * DM;
-template <int RD, int RM, bool WG>
+template <int NHP> constexpr int sz_dec_layer() { return 2 * sz_attn<NHP>() + SZ_FFN + 6 * DM; }
+template <int RD, int RM, bool WG, int NHP>
 DEV void decoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
-                       int Ld, int Lm, int activation, const f32x4 (&mem)[2][4], f32x4 (&x)[2][4]) {
-  float* Qb = region_q<WG>(smem, R);
-  float* Kb = region_k<WG>(smem, R);
-  float* Vb = region_v<WG>(smem, R);
+                       int Ld, int Lm, int activation, const Act& mem, Act& x) {
+  constexpr int SZ_ATTN = sz_attn<NHP>();
+  float* Qb = region_q<WG, NHP>(smem, R);
+  float* Kb = region_k<WG, NHP>(smem, R);
+  float* Vb = region_v<WG, NHP>(smem, R);
   const float* wc = w + SZ_ATTN;       // cross attention
   const float* wf = w + 2 * SZ_ATTN;   // conv1 | conv2
   const float* nw = wf + SZ_FFN;
   WFrag A;
   NormParams n;
-  f32x4 t[2][4], y[2][4];
+  Act t, y;
   // causal self attention
-  project_qkv<RD, RD, WG>(w, st, smem, R, ln, x, x, Ld, Ld, t);
-  attention<RD, RD, WG>(t, Qb, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
+  project_qkv<RD, RD, WG, NHP>(w, st, smem, R, ln, x, x, Ld, Ld, t);
+  attention<RD, RD, WG, NHP>(t, Qb, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
-  next_weights<WG>(A, st, w + 3 * SZ_LIN, ln, &n, nw);  // output projection, norm1
-  wmul<RD>(A, y, t);
+  next_weights<WG, 4, NHP>(A, st, w + 3 * sz_qkv<NHP>(), ln, &n, nw);  // output projection, norm1
+  wmul<RD, 4, NHP>(A, y, t);
   PROF_MARK(ln, P_OPROJ);
   add_into<RD>(x, t);
   layer_norm<RD>(x, n, ln);
   PROF_MARK(ln, P_ADDLN);
   // cross attention: queries from x, keys / values from the encoder memory
-  project_qkv<RD, RM, WG>(wc, st, smem, R, ln, x, mem, Ld, Lm, t);
-  attention<RD, RM, WG>(t, Qb, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
+  project_qkv<RD, RM, WG, NHP>(wc, st, smem, R, ln, x, mem, Ld, Lm, t);
+  attention<RD, RM, WG, NHP>(t, Qb, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
-  next_weights<WG>(A, st, wc + 3 * SZ_LIN, ln, &n, nw + 2 * DM);  // output projection, norm2
-  wmul<RD>(A, y, t);
+  next_weights<WG, 4, NHP>(A, st, wc + 3 * sz_qkv<NHP>(), ln, &n, nw + 2 * DM);  // output projection, norm2
+  wmul<RD, 4, NHP>(A, y, t);
   PROF_MARK(ln, P_OPROJ);
   add_into<RD>(x, t);
   layer_norm<RD>(x, n, ln);
@@ -805,14 +825,14 @@ constexpr int SZ_DISTIL = 3 * DM * DM + 3 * DM;
 // shifted by that tap.
 template <int RT, bool WG>  // tiles covering L + 2 conv outputs
 DEV int distil(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln, int L,
-               f32x4 (&x)[2][4]) {
+               Act& x) {
   float* Xb = smem;            // L input rows
   float* Yb = smem + R * LDW;  // L + 2 activated conv outputs (R + L + 2 rows in all)
   wave_sync();
   store_rows<RT>(Xb, ln, x, L);
   wave_sync();
   const int Lc = L + 2;
-  f32x4 y[2][4];
+  Act y;
   if (WG) {
     NormParams ab;  // gm = alpha, bt = beta
 #pragma unroll
@@ -912,7 +932,7 @@ DEV int distil(const float* __restrict__ w, Stage& st, float* smem, int R, const
   wave_sync();
   const int Lo = (Lc - 1) / 2 + 1;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < MAXT; ++rt) {
     if (rt < RT) {
       int u = 16 * rt + ln.c;
       u = u < Lo ? u : Lo - 1;
@@ -935,7 +955,7 @@ DEV int distil(const float* __restrict__ w, Stage& st, float* smem, int R, const
 // table. Block: w[3][64][c_in] (tap-major) | bias[64] | pe[L][64].  NKB = c_in / 16.
 template <int RT, int NKB>
 DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float* smem,
-               const Lane ln, int lane, int L, f32x4 (&x)[2][4]) {
+               const Lane ln, int lane, int L, Act& x) {
   constexpr int CIN = 16 * NKB;
   constexpr int XW = CIN + 4;  // staging row stride
   wave_sync();
@@ -994,8 +1014,8 @@ DEV void embed(const float* __restrict__ w, const float* __restrict__ xg, float*
 // keep their value. Used for x[:, -inp_len:, :] and for the concatenation of the encoder
 // outputs (encoder.py:96-99). RS / RD: tiles of the source / destination that can be involved.
 template <int RS, int RD>
-DEV void move_rows(float* smem, const Lane ln, const f32x4 (&x)[2][4], int first, int n, int dst,
-                   f32x4 (&into)[2][4]) {
+DEV void move_rows(float* smem, const Lane ln, const Act& x, int first, int n, int dst,
+                   Act& into) {
   wave_sync();
   store_rows<RS>(smem, ln, x, first + n);
   wave_sync();
@@ -1021,7 +1041,7 @@ DEV void exchange_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 
 // tap() for a packed tile: rows 0.. belong to sequence b, rows 8.. to sequence b2 (-1: none).
 DEV void tap_packed(float*& taps, int B, int b, int b2, int rows, const Lane ln,
-                    const f32x4 (&x)[2][4]) {
+                    const Act& x) {
   if (!taps) return;
   const int bs = (ln.c >> 3) ? b2 : b, rl = ln.c & 7;
   if (bs >= 0 && rl < rows) {
@@ -1036,14 +1056,14 @@ DEV void tap_packed(float*& taps, int B, int b, int b2, int rows, const Lane ln,
 // both sequences fit one tile (rows 0.. and 8..); NT = 2: up to 10 outputs per sequence, tile s
 // holds those of sequence s. The pooled rows are packed again. Returns rows out.
 template <int NT>
-DEV int distil_packed(Stage& st, float* smem, const Lane ln, int L, f32x4 (&x)[2][4]) {
+DEV int distil_packed(Stage& st, float* smem, const Lane ln, int L, Act& x) {
   float* Xb = smem;             // 16 input rows
   float* Yb = smem + 16 * LDW;  // NT tiles of activated conv outputs
   wave_sync();
   store_rows<1>(Xb, ln, x, 16);
   wave_sync();
   const int Lc = L + 2;
-  f32x4 y[2][4];
+  Act y;
   NormParams ab;  // gm = alpha, bt = beta
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -1108,18 +1128,18 @@ struct Cursor {
 };
 
 // One encoder step on RT row tiles (RM: tiles of the memory).
-template <int RT, int RM, bool WG>
+template <int RT, int RM, bool WG, int NHP>
 DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem, int R, const Lane ln,
-                int b, f32x4 (&x)[2][4], f32x4 (&mem)[2][4]) {
+                int b, Act& x, Act& mem) {
   const int L = op.L;
   if (op.type == OP_LAYER) {
     float* amap = nullptr;
     if (cu.attn) {
-      amap = cu.attn + (size_t)b * NHEAD * L * L;
-      cu.attn += (size_t)a.B * NHEAD * L * L;
+      amap = cu.attn + (size_t)b * a.n_heads * L * L;
+      cu.attn += (size_t)a.B * a.n_heads * L * L;
     }
-    encoder_layer<RT, WG>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
-    if (!ABLATED(a, 8)) cu.w += SZ_ENC_LAYER;
+    encoder_layer<RT, WG, NHP>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
+    if (!ABLATED(a, 8)) cu.w += sz_enc_layer<NHP>();
     tap<RT>(cu.taps, a.B, b, L, ln, x);
   } else if (op.type == OP_DISTIL) {
     const int Lo = distil<RT, WG>(cu.w, st, smem, R, ln, L, x);
@@ -1142,18 +1162,18 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
 // One encoder step of the primary wave on a packed tile (sequences b and b2; b2 = -1: none).
 template <int RM>
 DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
-                       float* partner_smem, int R, const Lane ln, int b, int b2, f32x4 (&x)[2][4],
-                       f32x4 (&mem)[2][4]) {
+                       float* partner_smem, int R, const Lane ln, int b, int b2, Act& x,
+                       Act& mem) {
   const int L = op.L;
   if (op.type == OP_LAYER) {
     float *amap = nullptr, *amap2 = nullptr;
     if (cu.attn) {
-      if (b >= 0) amap = cu.attn + (size_t)b * NHEAD * L * L;
-      if (b2 >= 0) amap2 = cu.attn + (size_t)b2 * NHEAD * L * L;
-      cu.attn += (size_t)a.B * NHEAD * L * L;
+      if (b >= 0) amap = cu.attn + (size_t)b * a.n_heads * L * L;
+      if (b2 >= 0) amap2 = cu.attn + (size_t)b2 * a.n_heads * L * L;
+      cu.attn += (size_t)a.B * a.n_heads * L * L;
     }
-    encoder_layer<1, true>(cu.w, st, smem, R, ln, 16, a.activation, amap, x, L, amap2);
-    cu.w += SZ_ENC_LAYER;
+    encoder_layer<1, true, 4>(cu.w, st, smem, R, ln, 16, a.activation, amap, x, L, amap2);
+    cu.w += sz_enc_layer<4>();
     tap_packed(cu.taps, a.B, b, b2, L, ln, x);
   } else if (op.type == OP_DISTIL) {
     const int Lo = L + 2 <= 8 ? distil_packed<1>(st, smem, ln, L, x) : distil_packed<2>(st, smem, ln, L, x);
@@ -1173,12 +1193,12 @@ DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float
 // barriers, advances the cursors and collects its encoder outputs.
 template <int RM>
 DEV void run_op_partner(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
-                        const Lane ln, f32x4 (&mem)[2][4]) {
+                        const Lane ln, Act& mem) {
   const int L = op.L;
   if (op.type == OP_LAYER) {
     for (int k = 0; k < 6; ++k) stage_acquire(st);
-    if (cu.attn) cu.attn += (size_t)a.B * NHEAD * L * L;
-    cu.w += SZ_ENC_LAYER;
+    if (cu.attn) cu.attn += (size_t)a.B * a.n_heads * L * L;
+    cu.w += sz_enc_layer<4>();
     if (cu.taps) cu.taps += (size_t)a.B * L * DM;
   } else if (op.type == OP_DISTIL) {
     for (int k = 0; k < 3; ++k) stage_acquire(st);
@@ -1208,8 +1228,13 @@ DEV void run_op_partner(const Op op, const KArgs& a, Cursor& cu, Stage& st, floa
 // WG = false: a workgroup is one wave; every wave loads its weights from global memory.
 // WG = true: a workgroup is 8 waves that keep in step through the weight staging (Stage);
 // waves beyond the batch compute a copy of the last sequence and store nothing.
-template <int RD, int RM, bool WG>
-__global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void informer_kernel(const KArgs a) {
+// RE: row tiles of the longest encoder step (2: sequences of up to 30 slots; 3: up to 46).
+// NHP: head pairs (4: up to 8 heads, 6: up to 12). The instantiations with three row tiles or
+// six head pairs ("large": the one-wave shape only) get the register budget of one wave per SIMD.
+template <int RE, int RD, int RM, bool WG, int NHP>
+__global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
+                             (WG || RE > 2 || RD > 2 || NHP > 4) ? 1 : CET_WPS) void informer_kernel(const KArgs a) {
+  static_assert(!WG || (RE <= 2 && RD <= 2 && NHP == 4), "the workgroup shape serves the 64-wide, 8-head family");
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   const int lane = threadIdx.x & 63;
   const int wave = WG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -1224,13 +1249,13 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   const int prof_slot = seq / prof_stride;
   const bool prof_on = valid && seq % prof_stride == 0 && prof_slot < PROF_SAMPLES;
   Lane ln{lane & 15, lane >> 4, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)), a.ln_inv_n, a.ln_pad,
-          a.attn_c};
+          a.attn_c, a.n_heads};
   ln.prof = prof_on ? a.prof + (size_t)prof_slot * PROF_MAXM : nullptr;
   ln.pidx = &prof_idx;
   PROF_MARK(ln, P_OTHER);
 #else
   Lane ln{lane & 15, lane >> 4, (unsigned)((lane & 15) * DM + 4 * (lane >> 4)), a.ln_inv_n, a.ln_pad,
-          a.attn_c};
+          a.attn_c, a.n_heads};
 #endif
 #ifdef CET_EXP
   ln.ablate = a.ablate;
@@ -1243,9 +1268,9 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   for (int i = lane; i < a.wave_lds_floats / 4; i += 64) st4(smem + 4 * i, zero4());
 
   Cursor cu{a.w, valid ? a.attn : nullptr, valid ? a.taps : nullptr};
-  f32x4 x[2][4], mem[2][4];
+  Act x, mem;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < MAXT; ++rt)
 #pragma unroll
     for (int m = 0; m < 4; ++m) x[rt][m] = mem[rt][m] = zero4();
 
@@ -1253,7 +1278,11 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
   {
     const int L = a.seq_len;
     const float* xg = a.x_enc + (size_t)b * L * a.enc_in;
-    if (L > 16) {
+    if (RE > 2 && L > 32) {
+      if (a.enc_in == 16) embed<RE, 1>(cu.w, xg, smem, ln, lane, L, x);
+      else embed<RE, 2>(cu.w, xg, smem, ln, lane, L, x);
+      tap<RE>(cu.taps, a.B, b, L, ln, x);
+    } else if (L > 16) {
       if (a.enc_in == 16) embed<2, 1>(cu.w, xg, smem, ln, lane, L, x);
       else embed<2, 2>(cu.w, xg, smem, ln, lane, L, x);
       tap<2>(cu.taps, a.B, b, L, ln, x);
@@ -1271,9 +1300,11 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
 
   // ---- encoder stack (encoder.py:87-101) ---------------------------------------------
   int i = 0;
-  for (; i < a.n_ops2; ++i) run_op<2, RM, WG>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  if (RE > 2)
+    for (; i < a.n_ops3; ++i) run_op<RE, RM, WG, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  for (; i < a.n_ops2; ++i) run_op<2, RM, WG, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
   const int n_plain = WG ? a.n_pack0 : a.n_ops;
-  for (; i < n_plain; ++i) run_op<1, RM, WG>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  for (; i < n_plain; ++i) run_op<1, RM, WG, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
   if (WG && i < a.n_ops) {
     // hand the partner's rows to the primary (see "two sequences in one tile")
     const int L0 = a.ops[i].L;
@@ -1312,8 +1343,8 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64, WG ? 1 : CET_WPS) void inf
     PROF_MARK(ln, P_EMBED);
   }
   for (int l = 0; l < a.d_layers; ++l) {
-    decoder_layer<RD, RM, WG>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
-    if (!ABLATED(a, 8)) cu.w += SZ_DEC_LAYER;
+    decoder_layer<RD, RM, WG, NHP>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
+    if (!ABLATED(a, 8)) cu.w += sz_dec_layer<NHP>();
     tap<RD>(cu.taps, a.B, b, Ld, ln, x);
   }
   layer_norm<RD>(x, cu.w, cu.w + DM, ln);
@@ -1370,9 +1401,13 @@ struct InformerModel {
   bool pack = true;
 };
 
+// Head pairs the kernels run a model with: 4 (up to 8 heads) or 6 (up to 12).
+static int head_pairs(const cet_informer_cfg& c) { return c.n_heads <= 8 ? 4 : 6; }
+
 static bool supported(const cet_informer_cfg& c) {
-  // narrower models run zero-padded to the kernels' 64 features and 8 heads of 8 (widen())
-  if (c.n_heads != NHEAD || c.d_model < NHEAD || c.d_model > DM || c.d_ff < 1 || c.d_ff > DM) return false;
+  // models run zero-padded to the kernels' 64 features and 8 or 12 heads of 8 features (widen())
+  if (c.n_heads < 1 || c.n_heads > 12 || c.d_model < c.n_heads || c.d_model > DM) return false;
+  if (c.d_model / c.n_heads > HDIM || c.d_ff < 1 || c.d_ff > DM) return false;
   if (c.enc_in != 16 && c.enc_in != 32) return false;
   if (c.dec_in != 16 && c.dec_in != 32) return false;
   if (c.c_out < 4 || c.c_out > 64 || c.c_out % 4) return false;
@@ -1427,7 +1462,7 @@ static bool plan(const cet_informer_cfg& c, Dims& d) {
 size_t informer_blob_size(const cet_informer_cfg* c) {
   Dims d;
   if (!supported(*c) || !plan(*c, d)) return 0;
-  const size_t D = c->d_model, F = c->d_ff, HE = (size_t)(c->d_model / NHEAD) * NHEAD;
+  const size_t D = c->d_model, F = c->d_ff, HE = (size_t)(c->d_model / c->n_heads) * c->n_heads;
   const size_t attn = 3 * (HE * D + HE) + D * HE + D, ffn = F * D + F + D * F + D;
   size_t n = D * c->enc_in * 3 + D + (size_t)c->seq_len * D;
   n += D * c->dec_in * 3 + D + (size_t)(c->label_len + c->pred_len) * D;
@@ -1456,19 +1491,20 @@ static void conv_taps_major(const float* src, int cout, int cin, std::vector<flo
       for (int c = 0; c < cin; ++c) dst.push_back(src[((size_t)o * cin + c) * 3 + j]);
 }
 
-// Zero-pads a model with d_model < 64 (and/or d_ff < 64, d_keys < 8) to the 64-wide layout the
-// kernels are built for, in the caller's tensor order. Model features d and FFN features f keep
-// their index; dimension e of head h moves to 8 h + e. Padded rows / columns, biases, LayerNorm
-// and BatchNorm scales are zero (BatchNorm variance one), so padded features are exactly zero
-// everywhere; LayerNorm and the attention scale take the real sizes from the kernel arguments.
+// Zero-pads a model to the layout the kernels are built for, in the caller's tensor order: 64
+// model and FFN features (d and f keep their index), and 8 features per head, dimension e of
+// head h at 8 h + e of a Q / K / V row of HQ = 16 * head_pairs features. Padded rows / columns,
+// biases, LayerNorm and BatchNorm scales are zero (BatchNorm variance one), so padded features
+// are exactly zero everywhere; LayerNorm and the attention scale take the real sizes from the
+// kernel arguments. A 64-wide model with 8 heads of 8 comes out as it went in.
 static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const float* p) {
-  const int D = c.d_model, F = c.d_ff, E = D / NHEAD, HE = E * NHEAD;
+  const int D = c.d_model, F = c.d_ff, E = D / c.n_heads, HE = E * c.n_heads;
+  const int HQ = 16 * head_pairs(c);
   std::vector<float> v;
   auto ident = [](int i) { return i; };
-  auto head = [E](int i) { return (i / E) * 8 + i % E; };
-  // matrix [rows][cols][taps] -> [64 or keep][64 or keep][taps]
-  auto mat = [&](int rows, int cols, int taps, bool pad_rows, bool pad_cols, auto rmap, auto cmap) {
-    const int R = pad_rows ? DM : rows, C = pad_cols ? DM : cols;
+  auto head = [E](int i) { return (i / E) * HDIM + i % E; };
+  // matrix [rows][cols][taps] -> [R][C][taps]
+  auto mat = [&](int rows, int cols, int taps, int R, int C, auto rmap, auto cmap) {
     const size_t base = v.size();
     v.resize(base + (size_t)R * C * taps, 0.f);
     for (int r = 0; r < rows; ++r)
@@ -1477,32 +1513,32 @@ static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const 
           v[base + ((size_t)rmap(r) * C + cmap(q)) * taps + t] = p[((size_t)r * cols + q) * taps + t];
     p += (size_t)rows * cols * taps;
   };
-  auto vec = [&](int n, auto map, float fill = 0.f) {
+  auto vec = [&](int n, auto map, float fill = 0.f, int N = DM) {
     const size_t base = v.size();
-    v.resize(base + DM, fill);
+    v.resize(base + N, fill);
     for (int i = 0; i < n; ++i) v[base + map(i)] = p[i];
     p += n;
   };
   auto attn = [&]() {
     for (int k = 0; k < 3; ++k) {
-      mat(HE, D, 1, true, true, head, ident);
-      vec(HE, head);
+      mat(HE, D, 1, HQ, DM, head, ident);
+      vec(HE, head, 0.f, HQ);
     }
-    mat(D, HE, 1, true, true, ident, head);
+    mat(D, HE, 1, DM, HQ, ident, head);
     vec(D, ident);
   };
   auto ffn = [&]() {
-    mat(F, D, 1, true, true, ident, ident);
+    mat(F, D, 1, DM, DM, ident, ident);
     vec(F, ident);
-    mat(D, F, 1, true, true, ident, ident);
+    mat(D, F, 1, DM, DM, ident, ident);
     vec(D, ident);
   };
   const int emb_in[2] = {c.enc_in, c.dec_in};
   const int emb_len[2] = {c.seq_len, c.label_len + c.pred_len};
   for (int s = 0; s < 2; ++s) {
-    mat(D, emb_in[s], 3, true, false, ident, ident);
+    mat(D, emb_in[s], 3, DM, emb_in[s], ident, ident);
     vec(D, ident);
-    mat(emb_len[s], D, 1, false, true, ident, ident);  // positional table rows
+    mat(emb_len[s], D, 1, emb_len[s], DM, ident, ident);  // positional table rows
   }
   for (int e = 0; e < d.n_enc; ++e) {
     const int el = d.enc_layers[e];
@@ -1513,7 +1549,7 @@ static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const 
     }
     if (c.distil)
       for (int l = 0; l < el - 1; ++l) {
-        mat(D, D, 3, true, true, ident, ident);
+        mat(D, D, 3, DM, DM, ident, ident);
         vec(D, ident);                              // conv bias
         vec(D, ident);                              // BatchNorm weight
         vec(D, ident);                              // BatchNorm bias
@@ -1531,7 +1567,7 @@ static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const 
   }
   vec(D, ident);
   vec(D, ident);
-  mat(c.c_out, D, 1, false, true, ident, ident);
+  mat(c.c_out, D, 1, c.c_out, DM, ident, ident);
   v.insert(v.end(), p, p + c.c_out);
   return v;
 }
@@ -1542,20 +1578,13 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   Dims d;
   if (!plan(*c_in, d)) return CET_ERR_UNSUPPORTED;
   if (n_in != informer_blob_size(c_in)) return CET_ERR_BLOB_SIZE;
-  // from here on everything is 64 wide
-  cet_informer_cfg c64 = *c_in;
-  c64.d_model = DM;
-  c64.d_ff = DM;
-  const cet_informer_cfg* c = &c64;
-  std::vector<float> wide;
-  const float* wsrc = wsrc_in;
-  size_t n = n_in;
-  if (c_in->d_model != DM || c_in->d_ff != DM) {
-    wide = widen(*c_in, d, wsrc_in);
-    wsrc = wide.data();
-    n = wide.size();
-    if (n != informer_blob_size(c)) return CET_ERR_BLOB_SIZE;
-  }
+  // from here on everything has the kernels' dimensions: 64 features, HQ-wide Q / K / V
+  const cet_informer_cfg* c = c_in;
+  const int NHP = head_pairs(*c_in);
+  const size_t HQ = 16 * NHP;
+  const std::vector<float> wide = widen(*c_in, d, wsrc_in);
+  const float* wsrc = wide.data();
+  const size_t n = wide.size();
 
   // Re-order the caller's (PyTorch-layout) blob into execution order.
   std::vector<float> v;
@@ -1577,7 +1606,9 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   // qk: the block is a query or key projection, whose output rows the workgroup kernel wants in
   // the order of qk_row() (see attention<.., QREG>).
   std::vector<float> blk;
+  const bool staged = NHP == 4;  // the workgroup kernel serves the 8-head family only
   auto add_block = [&](const float* lin, const float* norm, bool qk = false) {
+    if (!staged) return;
     const size_t base = blk.size();
     blk.resize(base + WBLK, 0.f);
     for (int r = 0; r < DM; ++r) {
@@ -1587,8 +1618,10 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
     }
     if (norm) std::copy(norm, norm + 2 * D, blk.begin() + base + WBLK_NORM);
   };
-  const size_t lin_sz = D * D + D;
-  const size_t layer_sz = 4 * (D * D + D) + 2 * (D * D + D) + 4 * D;
+  const size_t lin_sz = D * D + D;                      // Linear(64, 64): conv1 / conv2
+  const size_t qkv_sz = HQ * D + HQ;                    // Q / K / V projection
+  const size_t attn_sz = 3 * qkv_sz + D * HQ + D;       // + output projection
+  const size_t layer_sz = attn_sz + 2 * lin_sz + 4 * D;
   for (int e = 0; e < d.n_enc; ++e) {
     const int el = d.enc_layers[e];
     const float* layers = p;
@@ -1597,11 +1630,11 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
       v.insert(v.end(), layers + layer_sz * l, layers + layer_sz * (l + 1));
       {
         const float* lw = layers + layer_sz * l;       // q k v o conv1 conv2 norm1 norm2
-        const float* norms = lw + 6 * lin_sz;
-        for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr, k < 2);
-        add_block(lw + 3 * lin_sz, norms);
-        add_block(lw + 4 * lin_sz, nullptr);
-        add_block(lw + 5 * lin_sz, norms + 2 * D);
+        const float* norms = lw + attn_sz + 2 * lin_sz;
+        for (int k = 0; k < 3; ++k) add_block(lw + k * qkv_sz, nullptr, k < 2);
+        add_block(lw + 3 * qkv_sz, norms);
+        add_block(lw + attn_sz, nullptr);
+        add_block(lw + attn_sz + lin_sz, norms + 2 * D);
       }
       if (c->distil && l < el - 1) {
         const float* cw = convs + (size_t)l * (3 * D * D + 5 * D);
@@ -1636,14 +1669,14 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   }
   for (int l = 0; l < c->d_layers; ++l) {
     const float* lw = p;  // self q k v o | cross q k v o | conv1 conv2 | norm1 norm2 norm3
-    const float* norms = lw + 10 * lin_sz;
-    for (int k = 0; k < 3; ++k) add_block(lw + k * lin_sz, nullptr, k < 2);
-    add_block(lw + 3 * lin_sz, norms);
-    for (int k = 4; k < 7; ++k) add_block(lw + k * lin_sz, nullptr, k < 6);
-    add_block(lw + 7 * lin_sz, norms + 2 * D);
-    add_block(lw + 8 * lin_sz, nullptr);
-    add_block(lw + 9 * lin_sz, norms + 4 * D);
-    copy(10 * lin_sz + 6 * D);
+    const float* norms = lw + 2 * attn_sz + 2 * lin_sz;
+    for (int k = 0; k < 3; ++k) add_block(lw + k * qkv_sz, nullptr, k < 2);
+    add_block(lw + 3 * qkv_sz, norms);
+    for (int k = 0; k < 3; ++k) add_block(lw + attn_sz + k * qkv_sz, nullptr, k < 2);
+    add_block(lw + attn_sz + 3 * qkv_sz, norms + 2 * D);
+    add_block(lw + 2 * attn_sz, nullptr);
+    add_block(lw + 2 * attn_sz + lin_sz, norms + 4 * D);
+    copy(2 * attn_sz + 2 * lin_sz + 6 * D);
   }
   copy(2 * D);  // decoder norm
   {
@@ -1662,7 +1695,7 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   if (!m) return CET_ERR_ALLOC;
   m->cfg = *c_in;
   m->d = d;
-  for (int i = 0; i < d.n_attn; ++i) m->attn_per_sample += (size_t)NHEAD * d.attn_len[i] * d.attn_len[i];
+  for (int i = 0; i < d.n_attn; ++i) m->attn_per_sample += (size_t)c_in->n_heads * d.attn_len[i] * d.attn_len[i];
   for (int i = 0; i < d.n_taps; ++i) m->taps_per_sample += (size_t)d.tap_rows[i] * DM;
   m->n_blocks = (int)(blk.size() / WBLK);
   if (const char* k = getenv("CET_INFORMER_KERNEL")) m->kernel_choice = k[0] == 'o' ? 1 : (k[0] == 'w' ? 2 : 0);
@@ -1670,15 +1703,15 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   hipError_t e = hipGetDevice(&m->device);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&m->cus, hipDeviceAttributeMultiprocessorCount, m->device);
   // the workgroup kernel's dynamic LDS exceeds the default limit: raised once per device, here
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<1, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<1, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 1, 1, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 1, 2, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 2, 1, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&informer_kernel<2, 2, 2, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) e = hipMalloc(&m->dev_blob, v.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(m->dev_blob, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc(&m->dev_blocks, blk.size() * sizeof(float));
-  if (e == hipSuccess)
+  if (e == hipSuccess && !blk.empty()) e = hipMalloc(&m->dev_blocks, blk.size() * sizeof(float));
+  if (e == hipSuccess && !blk.empty())
     e = hipMemcpy(m->dev_blocks, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     if (m->dev_blob) (void)hipFree(m->dev_blob);
@@ -1718,10 +1751,11 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   for (int i = 0; i < 8; ++i) a.enc_layers[i] = m->d.enc_layers[i];
   // Steps of the encoder stack (encoder.py:87-101).
   {
-    int n = 0, cur = m->d.seq_len, inp_len = m->d.seq_len, mem_rows = 0, n2 = 0;
+    int n = 0, cur = m->d.seq_len, inp_len = m->d.seq_len, mem_rows = 0, n2 = 0, n3 = 0;
     auto push = [&](int type, int L, int p, int q, int need) {
       a.ops[n] = Op{(unsigned char)type, (unsigned char)L, (unsigned char)p, (unsigned char)q};
       if (need > 16) n2 = n + 1;
+      if (need > 32) n3 = n + 1;
       ++n;
     };
     for (int e = 0; e < m->d.n_enc; ++e) {
@@ -1743,6 +1777,7 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     }
     a.n_ops = n;
     a.n_ops2 = n2;
+    a.n_ops3 = n3;
     a.mem_rows = mem_rows;
     // Packed tail of the step list: from the first step on after which every layer and distil
     // step has at most 8 rows per sequence and nothing is sliced.
@@ -1764,10 +1799,16 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   int R = m->d.seq_len > Ld ? m->d.seq_len : Ld;
   if (R < m->d.mem_rows) R = m->d.mem_rows;
   if (R < 12) R = 12;
+  // "large": three row tiles somewhere or six head pairs; one-wave shape, one instantiation per
+  // head-pair count with three decoder and two memory tiles (padded tiles hold finite rows).
+  const int NHP = head_pairs(m->cfg);
+  const bool large = NHP > 4 || a.n_ops3 > 0 || m->d.seq_len > 32 || Ld > 32;
+  if (large && R < 24) R = 24;  // padded key tiles are read up to row 47 of the K | V regions
   a.region_rows = R;
+  a.n_heads = m->cfg.n_heads;
   a.ln_inv_n = 1.0f / (float)m->cfg.d_model;
   a.ln_pad = (float)(DM - m->cfg.d_model);
-  a.attn_c = (float)(1.0 / sqrt((double)(m->cfg.d_model / NHEAD))) * 1.44269504088896340736f;
+  a.attn_c = (float)(1.0 / sqrt((double)(m->cfg.d_model / m->cfg.n_heads))) * 1.44269504088896340736f;
   a.wblk = m->dev_blocks;
   a.n_blk = m->n_blocks;
 #ifdef CET_EXP
@@ -1797,7 +1838,7 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   // 8 x CUs sequences; the one-wave kernel spreads single waves over all CUs and finishes sooner
   // as long as every SIMD holds at most one of them (measured: 0.23 vs 0.27 ms at 4 sequences
   // per CU, 0.32 vs 0.28 ms at 5).
-  const bool wg = wg_lds <= 160 * 1024 && !force_one && (force_wg || B > 4 * m->cus);
+  const bool wg = !large && m->n_blocks > 0 && wg_lds <= 160 * 1024 && !force_one && (force_wg || B > 4 * m->cus);
 #ifdef CET_PROF
   static unsigned long long* prof_dev = nullptr;
   const size_t prof_bytes = (size_t)PROF_SAMPLES * PROF_MAXM * sizeof(unsigned long long);
@@ -1811,20 +1852,23 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     a.region_rows = R_wg;
     const dim3 grid((unsigned)((B + WG_WAVES - 1) / WG_WAVES)), block(64 * WG_WAVES);
 #define CET_LAUNCH_WG(RD_, RM_) \
-  hipLaunchKernelGGL((informer_kernel<RD_, RM_, true>), grid, block, wg_lds, stream, a)
+  hipLaunchKernelGGL((informer_kernel<2, RD_, RM_, true, 4>), grid, block, wg_lds, stream, a)
     if (!d2 && !m2) CET_LAUNCH_WG(1, 1);
     else if (!d2 && m2) CET_LAUNCH_WG(1, 2);
     else if (d2 && !m2) CET_LAUNCH_WG(2, 1);
     else CET_LAUNCH_WG(2, 2);
 #undef CET_LAUNCH_WG
   } else {
-    a.wave_lds_floats = 3 * R * LDW;
+    a.wave_lds_floats = 3 * R * (16 * NHP + 4);
     const size_t lds = (size_t)a.wave_lds_floats * sizeof(float);
+    if (lds > 64 * 1024) return CET_ERR_UNSUPPORTED;  // cannot happen within supported()'s limits
     const dim3 grid((unsigned)B), block(64);
-    if (!d2 && !m2) hipLaunchKernelGGL((informer_kernel<1, 1, false>), grid, block, lds, stream, a);
-    else if (!d2 && m2) hipLaunchKernelGGL((informer_kernel<1, 2, false>), grid, block, lds, stream, a);
-    else if (d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 1, false>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((informer_kernel<2, 2, false>), grid, block, lds, stream, a);
+    if (large && NHP == 6) hipLaunchKernelGGL((informer_kernel<3, 3, 2, false, 6>), grid, block, lds, stream, a);
+    else if (large) hipLaunchKernelGGL((informer_kernel<3, 3, 2, false, 4>), grid, block, lds, stream, a);
+    else if (!d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 1, 1, false, 4>), grid, block, lds, stream, a);
+    else if (!d2 && m2) hipLaunchKernelGGL((informer_kernel<2, 1, 2, false, 4>), grid, block, lds, stream, a);
+    else if (d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 2, 1, false, 4>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((informer_kernel<2, 2, 2, false, 4>), grid, block, lds, stream, a);
   }
   CET_HIP(hipGetLastError());
 #ifdef CET_PROF

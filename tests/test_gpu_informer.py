@@ -164,6 +164,32 @@ def test_more_shipped_checkpoints(name, cls):
     assert np.abs(attns[0][0].cpu().numpy() - v[f"{name}/attn_0"]).max() < TOL_ATTN
 
 
+def test_shipped_12_head_35_slot_checkpoint(kernel_variant, oracle):
+    """HPC/TrainedTransformers/InformerStack_5x_d_model64_n_heads12_..._seq_len35_label_len20_
+    pred_len5_..._uplink.pt: 12 heads of 64 // 12 = 5 features (60-wide projections,
+    models/attn.py:126-133), 35-slot history (three 16-row tiles), 25-row decoder input. Every
+    stage, every attention map and the prediction against the imported reference; the library
+    serves this family with its one-wave launch shape whatever shape is asked for."""
+    v = load_npz("informer_h12.npz")
+    args = (16, 16, 16, 35, 20, 5, 5, 64, 12, 4, 3, 64, 0.05, "full", "fixed", "gelu", True, True)
+    m = build("InformerStack", args, sub_dict(v, "h12/sd"))
+    pred, taps, attn = run_taps(m, v["h12/x_enc"], v["h12/x_dec"])
+    B = v["h12/x_enc"].shape[0]
+    rows = oracle.tap_rows(m._cfg)
+    for i, t in enumerate(oracle.split_taps(taps, rows, B, 64)):
+        err = np.abs(t - v[f"h12/tap_{i}"]).max()
+        assert err < TOL_STAGE, f"stage {i} (rows {rows[i]}): {err}"
+    for i, a in enumerate(oracle.split_attn(attn, oracle.attn_lengths(m._cfg), B, 12)):
+        assert a.shape == v[f"h12/attn_{i}"].shape
+        assert np.abs(a - v[f"h12/attn_{i}"]).max() < TOL_ATTN, f"attention map {i}"
+    assert np.abs(pred - v["h12/pred"]).max() < TOL_PRED
+    # through the module API, with the reference's nesting of the maps
+    out, attns = m.cuda()(torch.from_numpy(v["h12/x_enc"]).cuda(), torch.from_numpy(v["h12/x_dec"]).cuda())
+    assert np.array_equal(out.cpu().numpy(), pred)
+    assert [a.shape[1:] for a in attns[0]] == [(12, 35, 35), (12, 19, 19), (12, 11, 11), (12, 7, 7)]
+    assert [a.shape[1:] for a in attns[1]] == [(12, 7, 7), (12, 5, 5), (12, 4, 4)]
+
+
 def test_e2e_class_is_the_same_wiring():
     """InformerStack_e2e (LocalSimulations/models/model.py:84-158) differs from InformerStack in
     its training target only: same state_dict keys, same outputs."""

@@ -51,8 +51,14 @@ def test_unsupported_configurations_are_refused():
     for narrow in (32, 54):  # narrower models are widened with zeros by the library
         cfg.d_model = narrow
         assert L.cet_informer_blob_size(ctypes.byref(cfg)) > 0
-    cfg.d_model, cfg.n_heads = 64, 4
+    cfg.d_model, cfg.n_heads = 64, 4  # 16 features per head: more than the kernels' 8
     assert L.cet_informer_blob_size(ctypes.byref(cfg)) == 0
+    cfg.n_heads = 12  # 12 heads of 5 features: served
+    assert L.cet_informer_blob_size(ctypes.byref(cfg)) == blobs.informer_blob_len(cfg)
+    cfg.n_heads, cfg.seq_len = 8, 47  # with distilling, 46 slots is the longest history
+    assert L.cet_informer_blob_size(ctypes.byref(cfg)) == 0
+    cfg.seq_len, cfg.label_len = 40, 43  # decoder input of 48 rows: served
+    assert L.cet_informer_blob_size(ctypes.byref(cfg)) == blobs.informer_blob_len(cfg)
     rc = L.cet_rnn_create(1, 16, 16, 100, 2, dummy.ctypes.data_as(ctypes.c_void_p), 4, ctypes.byref(h))
     assert rc == 2
     cfg = cfg_from_args(DEFAULT_ARGS, True)
