@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CET_LIB") or os.path.join(_HERE, "csrc", "libcet.so")
 
 ERR_NAMES = {0: "CET_OK", 1: "CET_ERR_INVALID_ARG", 2: "CET_ERR_UNSUPPORTED", 3: "CET_ERR_HIP",
-             4: "CET_ERR_ALLOC", 5: "CET_ERR_BLOB_SIZE"}
+             4: "CET_ERR_ALLOC", 5: "CET_ERR_BLOB_SIZE", 6: "CET_ERR_TOO_LARGE"}
 
 # Every symbol include/cet.h declares; tests check that the library exports all of them.
 EXPORTS = (
@@ -19,7 +19,7 @@ EXPORTS = (
     "cet_informer_blob_size", "cet_informer_create", "cet_informer_attn_size",
     "cet_informer_forward", "cet_informer_select", "cet_informer_taps_size",
     "cet_informer_forward_taps",
-    "cet_rnn_blob_size", "cet_rnn_create", "cet_rnn_rollout", "cet_lmmse", "cet_lmmse_direct",
+    "cet_rnn_blob_size", "cet_rnn_create", "cet_rnn_rollout", "cet_rnn_select", "cet_lmmse", "cet_lmmse_direct",
     "cet_lmmse_llr", "cet_lmmse_block", "cet_lmmse_block_llr", "cet_lmmse_grid", "cet_ls_nn", "cet_nmse_sums", "cet_qpsk_bit_errors",
 )
 
@@ -69,6 +69,7 @@ def lib():
     L.cet_rnn_blob_size.argtypes = [ctypes.c_int] * 5
     L.cet_rnn_create.argtypes = [ctypes.c_int] * 5 + [fp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.cet_rnn_rollout.argtypes = [vp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
+    L.cet_rnn_select.argtypes = [vp, ctypes.c_int]
     L.cet_lmmse.argtypes = [fp, fp, ctypes.c_int, ctypes.c_float, fp, fp, fp, ctypes.c_long,
                             ctypes.c_int, ctypes.c_int, vp]
     L.cet_lmmse_direct.argtypes = L.cet_lmmse.argtypes

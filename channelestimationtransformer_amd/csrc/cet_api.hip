@@ -29,6 +29,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
 void rnn_destroy(RnnModel* m);
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream);
+void rnn_select(RnnModel* m, int variant);
 
 // A handle's weights live on the device that was current when it was created; launching from
 // another device would read them across GPUs (or fault without peer access).
@@ -53,6 +54,9 @@ const char* cet_strerror(int code) {
     case CET_ERR_HIP: return "HIP runtime call failed";
     case CET_ERR_ALLOC: return "allocation failed";
     case CET_ERR_BLOB_SIZE: return "weight blob length does not match the configuration";
+    case CET_ERR_TOO_LARGE:
+      return "batch too large for the requested kernel or buffer (hidden-split rollout: ceil(B / 16) * "
+             "hidden / 16 workgroups must not exceed the CU count)";
     default: return "unknown error code";
   }
 }
@@ -162,6 +166,12 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
   if (const int rc = check_device(h)) return rc;
   return rnn_rollout(static_cast<RnnModel*>(h->impl), x, out, B, seq_len, pred_len,
                      static_cast<hipStream_t>(stream));
+}
+
+int cet_rnn_select(cet_handle h, int kernel) {
+  if (!h || h->kind != HANDLE_RNN || kernel < 0 || kernel > 2) return CET_ERR_INVALID_ARG;
+  rnn_select(static_cast<RnnModel*>(h->impl), kernel);
+  return CET_OK;
 }
 
 // `x_hat` receives LLRs when `llr` is set (no_eff is then not written and may be null).

@@ -1450,7 +1450,7 @@ static bool plan(const cet_informer_cfg& c, Dims& d) {
     mem_rows += L;
     inp_len /= 2;
   }
-  if (mem_rows > MAXROWS) return false;
+  if (mem_rows > 32) return false;  // the cross-attention memory spans at most two row tiles
   d.mem_rows = mem_rows;
   d.tap_rows[d.n_taps++] = mem_rows;
   d.tap_rows[d.n_taps++] = Ld;

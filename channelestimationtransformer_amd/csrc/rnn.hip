@@ -430,6 +430,376 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
 #endif
 }
 
+
+// ---- hidden-split rollout for small batches -------------------------------------------------
+// The kernel above gives a workgroup 32 sequences and ALL hidden units: per time step it streams
+// the whole weight set through one CU, so a rollout of 64 sequences (2 workgroups) takes as long
+// as one of 8192. Below, the hidden units are split instead: workgroup (tile, ug) owns 16
+// sequences and hidden units [16 ug, 16 ug + 16) of every layer, keeps exactly the weight rows of
+// those units in REGISTERS for the whole rollout (4 waves split the k range; nothing is streamed
+// per step) and exchanges hidden states with the H / 16 - 1 other workgroups of its sequence tile
+// through a scratch buffer in global memory, once per layer and time step:
+//   * gates^T[16 units][16 sequences] = W * [x ; h]^T on v_mfma_f32_16x16x4_f32, k split over the
+//     4 waves, partial sums meet in LDS, wave 0 applies the cell update for the 256 (unit,
+//     sequence) pairs and keeps the workgroup's own h / c slice in registers;
+//   * publish: wave 0 stores the slice (1 KiB, whole 128-byte lines per store instruction) with
+//     agent-scope (write-through) stores, waits for them, and one lane adds 1 to the arrival
+//     counter of (tile, layer);
+//   * fetch: one lane polls that counter with agent-scope loads until all H / 16 workgroups of
+//     the tile have arrived at this step (bounded: a wait that does not end marks the workgroup
+//     dead and every later wait returns at once, so the grid always drains), a workgroup barrier
+//     follows, then every thread reads the published slices with agent-scope loads into LDS.
+//   The slices of a step go to the buffer of the step's parity; a workgroup can be at most one
+//   step ahead of the slowest one of its tile, so two buffers suffice.
+//   * the encoder and decoder Linears are small and computed redundantly by every workgroup, so
+//     the closed-loop feedback needs no further exchange.
+// The grid (tiles x H / 16 workgroups, one per CU) must be resident at once: the launcher only
+// picks this kernel while the grid fits the device's CU count.
+constexpr int ST = 16;        // sequences per workgroup
+constexpr int SPIN_LIMIT = 1 << 20;  // polls of about a microsecond each: a second or two
+
+DEV f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct SArgs {
+  const float* w_ih[3];  // [G*H][in_l]   PyTorch layouts, device
+  const float* w_hh[3];  // [G*H][H]
+  const float* bias;     // [layer][2][G*H]   (b_ih, b_hh)
+  const float* enc_w;    // [FP][FP] zero padded (row = encoder output unit)
+  const float* enc_b;    // [FP]
+  const float* dec_w;    // [FP][H] zero padded (row = feature)
+  const float* dec_b;    // [FP]
+  const float* x;        // [B][seq][F]
+  float* out;            // [B][pred][F]
+  float* hx;             // exchange: [tile][layer][parity][unit group][256]
+  unsigned* cnt;         // arrival counters [tile][layer], zero at launch
+  int B, seq_len, pred_len, F, I;
+};
+
+template <int KIND, int H, int NL>
+__global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
+  constexpr int G = Cell<KIND>::G, NACC = Cell<KIND>::NACC;
+  constexpr bool LSTM = KIND == CET_RNN_LSTM, GRU = KIND == CET_RNN_GRU;
+  constexpr int P = H / 16;            // workgroups per sequence tile
+  constexpr int HB = H / 16;           // k blocks of 16 in a hidden state
+  constexpr int HS = H + 4;            // LDS row stride of a hidden state
+  constexpr int XS = FP + 4;           // LDS row stride of the input / encoder rows
+  constexpr int XB = FP / 16;          // k blocks of the (padded) encoder output and of the features
+  constexpr int JX = (XB + HB + 3) / 4;  // blocks of layer 0 per wave
+  constexpr int JH = (2 * HB + 3) / 4;   // blocks of a higher layer per wave
+
+  __shared__ __attribute__((aligned(16))) float xcur[ST * XS];   // this step's input features
+  __shared__ __attribute__((aligned(16))) float xe[ST * XS];     // encoder output (layer-0 input)
+  __shared__ __attribute__((aligned(16))) float hfull[NL][ST * HS];
+  __shared__ __attribute__((aligned(16))) float part[4][NACC > 2 ? NACC : 2][256];
+  __shared__ int dead;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x / P, ug = blockIdx.x % P;
+  const int b0 = tile * ST;
+  const int bc = b0 + c < a.B ? b0 + c : a.B - 1;  // tail tile: replay the last sequence
+
+  // ---- this wave's weights, in registers for the whole rollout --------------------------------
+  // Block b of a layer covers k = 16 b .. 16 b + 15 of [input ; hidden]; wave w owns blocks
+  // 4 j + w. Lane (c, g) holds, per gate, W[unit 16 ug + c][k = 16 b + 4 g + i], i = 0..3.
+  f32x4 w0[JX][G], wh[NL > 1 ? NL - 1 : 1][JH][G];
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int b = 4 * j + wave;
+#pragma unroll
+    for (int gt = 0; gt < G; ++gt) {
+      const int row = gt * H + 16 * ug + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b < XB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = 16 * b + 4 * g + i;
+          if (k < a.I) v[i] = a.w_ih[0][(size_t)row * a.I + k];
+        }
+      } else if (b < XB + HB) {
+        v = ld4(a.w_hh[0] + (size_t)row * H + 16 * (b - XB) + 4 * g);
+      }
+      w0[j][gt] = v;
+    }
+  }
+#pragma unroll
+  for (int l = 1; l < NL; ++l)
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      const int b = 4 * j + wave;
+#pragma unroll
+      for (int gt = 0; gt < G; ++gt) {
+        const int row = gt * H + 16 * ug + c;
+        const float* src = b < HB ? a.w_ih[l] + (size_t)row * H + 16 * b : a.w_hh[l] + (size_t)row * H + 16 * (b - HB);
+        wh[l - 1][j][gt] = b < 2 * HB ? ld4(src + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  // decoder rows (features) x this wave's k blocks of the top hidden state; encoder in wave 0
+  f32x4 wd[XB][HB / 4];
+#pragma unroll
+  for (int ft = 0; ft < XB; ++ft)
+#pragma unroll
+    for (int j = 0; j < HB / 4; ++j)
+      wd[ft][j] = ld4(a.dec_w + (size_t)(16 * ft + c) * H + 16 * (4 * j + wave) + 4 * g);
+  f32x4 we[XB][XB], be[XB], bd[XB];
+#pragma unroll
+  for (int it = 0; it < XB; ++it) {
+#pragma unroll
+    for (int kb = 0; kb < XB; ++kb) we[it][kb] = ld4(a.enc_w + (16 * it + c) * FP + 16 * kb + 4 * g);
+    be[it] = ld4(a.enc_b + 16 * it + 4 * g);
+    bd[it] = ld4(a.dec_b + 16 * it + 4 * g);
+  }
+  // biases of the own units (wave 0 applies them): lane (c, g) <-> units 16 ug + 4 g + i
+  f32x4 bsum[NL][NACC];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const float* bi = a.bias + (size_t)l * 2 * G * H;
+    const float* bh = bi + G * H;
+#pragma unroll
+    for (int gt = 0; gt < G; ++gt) {
+      const f32x4 v1 = ld4(bi + gt * H + 16 * ug + 4 * g), v2 = ld4(bh + gt * H + 16 * ug + 4 * g);
+      if (GRU && gt == 2) {
+        bsum[l][2] = v1;  // n gate: W_in x + b_in apart from W_hn h + b_hn
+        bsum[l][3] = v2;
+      } else {
+        bsum[l][gt] = v1 + v2;
+      }
+    }
+  }
+
+  for (int i = tid; i < NL * ST * HS; i += 256) (&hfull[0][0])[i] = 0.f;
+  for (int i = tid; i < ST * XS; i += 256) xcur[i] = xe[i] = 0.f;
+  if (tid == 0) dead = 0;
+  f32x4 hown[NL], cown[NL];  // wave 0: own slice of h (and c), units 4 g + i of sequence c
+#pragma unroll
+  for (int l = 0; l < NL; ++l) hown[l] = cown[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  float* const hx_tile = a.hx + (size_t)tile * NL * 2 * P * 256;
+  unsigned* const cnt_tile = a.cnt + tile * NL;
+
+  // Waits until every workgroup of the tile has published layer l of step t, then copies the
+  // layer's full hidden state into hfull[l].
+  // With l2 >= 0 the same for layer l2 of step t2 in the same round trip (the top layer's state of
+  // the step before, whose wait was put off until its first use).
+  auto fetch = [&](int l, int t, int l2 = -1, int t2 = 0) {
+    if (tid == 0 && !dead) {
+      const unsigned target = (unsigned)P * (unsigned)(t + 1), target2 = (unsigned)P * (unsigned)(t2 + 1);
+      int spins = 0;
+      while (__hip_atomic_load(cnt_tile + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target ||
+             (l2 >= 0 && __hip_atomic_load(cnt_tile + l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target2)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) {
+          dead = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    const int i = tid >> 6, ll = tid & 63;  // element tid of a slice: unit 4 (ll / 16) + i, sequence ll % 16
+    const int at = (ll & 15) * HS + 4 * (ll >> 4) + i;
+    const float* src = hx_tile + ((size_t)l * 2 + (t & 1)) * P * 256 + tid;
+    const float* src2 = hx_tile + ((size_t)(l2 >= 0 ? l2 : 0) * 2 + (t2 & 1)) * P * 256 + tid;
+    float v[P], v2[P];  // all loads of the round in flight together: one memory round trip
+#pragma unroll
+    for (int s = 0; s < P; ++s) v[s] = __hip_atomic_load(src + s * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (l2 >= 0) {
+#pragma unroll
+      for (int s = 0; s < P; ++s) v2[s] = __hip_atomic_load(src2 + s * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int s = 0; s < P; ++s) hfull[l][at + 16 * s] = v[s];
+    if (l2 >= 0) {
+#pragma unroll
+      for (int s = 0; s < P; ++s) hfull[l2][at + 16 * s] = v2[s];
+    }
+    __syncthreads();
+  };
+
+  const int n_steps = a.seq_len + a.pred_len - 1;
+  bool pending_top = false;
+  for (int t = 0; t < n_steps; ++t) {
+    // ---- input features (teacher forced) and encoder Linear, wave 0 ----------------------------
+    if (wave == 0) {
+      if (t < a.seq_len) {
+        for (int q = lane; q < ST * (a.F / 4); q += 64) {
+          const int sq = q / (a.F / 4), f4 = q % (a.F / 4);
+          const int bs = b0 + sq < a.B ? b0 + sq : a.B - 1;
+          st4(xcur + sq * XS + 4 * f4, ld4(a.x + ((size_t)bs * a.seq_len + t) * a.F + 4 * f4));
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < XB; ++it) {
+        f32x4 acc = be[it];
+#pragma unroll
+        for (int kb = 0; kb < XB; ++kb) {
+          const f32x4 bv = ld4(xcur + c * XS + 16 * kb + 4 * g);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = mfma16(we[it][kb][i], bv[i], acc);
+        }
+        st4(xe + c * XS + 16 * it + 4 * g, acc);
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (l == NL - 1 && pending_top) {  // only when no lower layer's fetch took it along (NL == 1)
+        fetch(NL - 1, t - 1);
+        pending_top = false;
+      }
+      // ---- partial gate sums over this wave's k blocks ---------------------------------------------
+      f32x4 acc[NACC];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (l == 0) {
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+          const int b = 4 * j + wave;
+          if (b < XB + HB) {
+            const bool is_x = b < XB;
+            const f32x4 bv = is_x ? ld4(xe + c * XS + 16 * b + 4 * g) : ld4(hfull[0] + c * HS + 16 * (b - XB) + 4 * g);
+#pragma unroll
+            for (int gt = 0; gt < G; ++gt) {
+              if (GRU && gt == 2) {
+                f32x4 ax = acc[2], ah = acc[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  if (is_x) ax = mfma16(w0[j][gt][i], bv[i], ax);
+                  else ah = mfma16(w0[j][gt][i], bv[i], ah);
+                }
+                acc[2] = ax;
+                acc[3] = ah;
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[gt] = mfma16(w0[j][gt][i], bv[i], acc[gt]);
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < JH; ++j) {
+          const int b = 4 * j + wave;
+          if (b < 2 * HB) {
+            const bool is_x = b < HB;
+            const f32x4 bv = is_x ? ld4(hfull[l - 1] + c * HS + 16 * b + 4 * g) : ld4(hfull[l] + c * HS + 16 * (b - HB) + 4 * g);
+#pragma unroll
+            for (int gt = 0; gt < G; ++gt) {
+              if (GRU && gt == 2) {
+                f32x4 ax = acc[2], ah = acc[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  if (is_x) ax = mfma16(wh[l > 0 ? l - 1 : 0][j][gt][i], bv[i], ax);
+                  else ah = mfma16(wh[l > 0 ? l - 1 : 0][j][gt][i], bv[i], ah);
+                }
+                acc[2] = ax;
+                acc[3] = ah;
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[gt] = mfma16(wh[l > 0 ? l - 1 : 0][j][gt][i], bv[i], acc[gt]);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) st4(&part[wave][q][4 * lane], acc[q]);
+      __syncthreads();
+      // ---- cell update of the own 16 x 16 slice and its publication, wave 0 --------------------------
+      if (wave == 0) {
+        f32x4 s[NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+          s[q] = ((ld4(&part[0][q][4 * lane]) + ld4(&part[1][q][4 * lane])) +
+                  (ld4(&part[2][q][4 * lane]) + ld4(&part[3][q][4 * lane]))) + bsum[l][q];
+        f32x4 hn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float hv;
+          if (KIND == CET_RNN_TANH) {
+            hv = tanhf_(s[0][i]);
+          } else if (GRU) {
+            const float rg = sigmoidf_(s[0][i]);
+            const float zg = sigmoidf_(s[1][i]);
+            const float ng = tanhf_(s[2][i] + rg * s[3][i]);
+            hv = (1.0f - zg) * ng + zg * hown[l][i];
+          } else {
+            const float ig = sigmoidf_(s[0][i]);
+            const float fg = sigmoidf_(s[1][i]);
+            const float gg = tanhf_(s[2][i]);
+            const float og = sigmoidf_(s[LSTM ? 3 : 0][i]);
+            const float cv = __fadd_rn(__fmul_rn(fg, cown[l][i]), __fmul_rn(ig, gg));
+            cown[l][i] = cv;
+            hv = og * tanhf_(cv);
+          }
+          hn[i] = hv;
+        }
+        hown[l] = hn;
+        float* dst = hx_tile + (((size_t)l * 2 + (t & 1)) * P + ug) * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)  // element i * 64 + lane: 256 contiguous bytes per store instruction
+          __hip_atomic_store(dst + i * 64 + lane, hn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt_tile + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (l < NL - 1) {
+        if (l == NL - 2 && pending_top) {  // the layer above needs both: one wait, one round trip
+          fetch(l, t, NL - 1, t - 1);
+          pending_top = false;
+        } else {
+          fetch(l, t);
+        }
+      } else {
+        pending_top = true;
+      }
+    }
+
+    // ---- decoder Linear on the new top hidden state: the prediction and the next input --------------
+    if (t >= a.seq_len - 1) {
+      fetch(NL - 1, t);
+      pending_top = false;
+      f32x4 dacc[XB];
+#pragma unroll
+      for (int ft = 0; ft < XB; ++ft) dacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < HB / 4; ++j) {
+        const f32x4 bv = ld4(hfull[NL - 1] + c * HS + 16 * (4 * j + wave) + 4 * g);
+#pragma unroll
+        for (int ft = 0; ft < XB; ++ft)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dacc[ft] = mfma16(wd[ft][j][i], bv[i], dacc[ft]);
+      }
+#pragma unroll
+      for (int ft = 0; ft < XB; ++ft) st4(&part[wave][ft][4 * lane], dacc[ft]);
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int ft = 0; ft < XB; ++ft) {
+          const f32x4 y = ((ld4(&part[0][ft][4 * lane]) + ld4(&part[1][ft][4 * lane])) +
+                           (ld4(&part[2][ft][4 * lane]) + ld4(&part[3][ft][4 * lane]))) + bd[ft];
+          st4(xcur + c * XS + 16 * ft + 4 * g, y);  // features 16 ft + 4 g + i of sequence c
+          const int f0 = 16 * ft + 4 * g;
+          if (ug == 0 && b0 + c < a.B && f0 < a.F)
+            st4(a.out + ((size_t)(b0 + c) * a.pred_len + (t - (a.seq_len - 1))) * a.F + f0, y);
+        }
+      }
+      // the next step's barrier orders these LDS writes before the encoder reads them (wave 0 does
+      // both) and the reads of `part` before it is written again
+    }
+  }
+  (void)bc;
+}
+
+// Scratch of the hidden-split kernel: arrival counters (one per tile and layer, in a block of
+// their own that is zeroed before every launch), then the exchange slices
+// [tile][layer][parity][unit group][256 floats].
+constexpr size_t SPLIT_CNT_FLOATS = 128;  // 512 B: room for 128 counters >= 32 tiles x 3 layers
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -439,6 +809,14 @@ struct RnnModel {
   int kind, F, I, H, layers, IP;
   float* dev = nullptr;  // one allocation; the pointers below point into it
   const float *wstream, *bias, *enc_w, *enc_b, *dec_w, *dec_b;
+  const float *w_ih[3], *w_hh[3];  // gate weights in their PyTorch layouts (hidden-split kernel)
+  int device = 0, cus = 0;
+  int variant = 0;  // 0: by batch size, 1: batch-tiled kernel, 2: hidden-split kernel
+  // Exchange buffer of the hidden-split kernel: allocated by the first rollout that needs it (or
+  // a larger one), kept until the handle is destroyed. Rollouts of one handle that overlap in time
+  // share it and would race.
+  mutable float* scratch = nullptr;
+  mutable size_t scratch_bytes = 0;
 };
 
 static int rnn_prepare(const RnnModel* m);  // per-device kernel attributes, defined with the launchers
@@ -457,6 +835,7 @@ static bool rnn_supported(int kind, int F, int I, int H, int layers) {
 void rnn_destroy(RnnModel* m) {
   if (!m) return;
   if (m->dev) (void)hipFree(m->dev);
+  if (m->scratch) (void)hipFree(m->scratch);
   delete m;
 }
 
@@ -541,6 +920,11 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   };
   const size_t o_stream = place(stream), o_bias = place(bias), o_ew = place(ew), o_eb = place(eb),
                o_dw = place(dw), o_db = place(db);
+  size_t o_ih[3] = {0, 0, 0}, o_hh[3] = {0, 0, 0};
+  for (int l = 0; l < layers; ++l) {
+    o_ih[l] = place(std::vector<float>(lw[l].w_ih, lw[l].w_ih + (size_t)G * H * lw[l].in));
+    o_hh[l] = place(std::vector<float>(lw[l].w_hh, lw[l].w_hh + (size_t)G * H * H));
+  }
   hipError_t e = hipMalloc(&m->dev, all.size() * sizeof(float));
   if (e == hipSuccess)
     e = hipMemcpy(m->dev, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -551,6 +935,17 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   m->wstream = m->dev + o_stream; m->bias = m->dev + o_bias; m->enc_w = m->dev + o_ew;
   m->enc_b = m->dev + o_eb; m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
+  for (int l = 0; l < 3; ++l) {
+    m->w_ih[l] = l < layers ? m->dev + o_ih[l] : nullptr;
+    m->w_hh[l] = l < layers ? m->dev + o_hh[l] : nullptr;
+  }
+  e = hipGetDevice(&m->device);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&m->cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  if (e != hipSuccess) {
+    rnn_destroy(m);
+    return hip_fail(e);
+  }
+  if (const char* k = getenv("CET_RNN_KERNEL")) m->variant = k[0] == 't' ? 1 : (k[0] == 's' ? 2 : 0);
   if (const int rc = rnn_prepare(m)) {
     rnn_destroy(m);
     return rc;
@@ -617,8 +1012,72 @@ static int rnn_prepare(const RnnModel* m) {
   return pf();
 }
 
+template <int KIND, int H, int NL>
+static int launch_split(const SArgs& a, int tiles, hipStream_t stream) {
+  hipLaunchKernelGGL((rnn_split_kernel<KIND, H, NL>), dim3((unsigned)(tiles * (H / 16))), dim3(256), 0,
+                     stream, a);
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+template <int KIND>
+static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, hipStream_t s) {
+#define CET_SPLIT_CASE(H_, NL_) \
+  if (m->H == H_ && m->layers == NL_) return launch_split<KIND, H_, NL_>(a, tiles, s);
+  CET_SPLIT_CASE(128, 1) CET_SPLIT_CASE(128, 2) CET_SPLIT_CASE(128, 3)
+  CET_SPLIT_CASE(256, 1) CET_SPLIT_CASE(256, 2) CET_SPLIT_CASE(256, 3)
+#undef CET_SPLIT_CASE
+  return CET_ERR_UNSUPPORTED;
+}
+
+// Workgroups of the hidden-split kernel for a batch, and whether they are all resident at once.
+static int split_tiles(int B) { return (B + ST - 1) / ST; }
+static bool split_fits(const RnnModel* m, int B, int max_wg) {
+  const long wg = (long)split_tiles(B) * (m->H / 16);
+  return wg <= m->cus && wg <= max_wg;
+}
+
+// The hidden-split rollout on `scratch` (device, SPLIT_CNT_FLOATS + tiles * layers * 2 * H / 16 *
+// 256 floats): zeroes the counters and launches.
+static int rollout_split(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                         float* scratch, hipStream_t stream) {
+  SArgs a{};
+  for (int l = 0; l < 3; ++l) {
+    a.w_ih[l] = m->w_ih[l];
+    a.w_hh[l] = m->w_hh[l];
+  }
+  a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b; a.dec_w = m->dec_w; a.dec_b = m->dec_b;
+  a.x = x; a.out = out; a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F; a.I = m->I;
+  a.cnt = reinterpret_cast<unsigned*>(scratch);
+  a.hx = scratch + SPLIT_CNT_FLOATS;
+  CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
+  const int tiles = split_tiles(B);
+  switch (m->kind) {
+    case CET_RNN_TANH: return launch_split_kind<CET_RNN_TANH>(m, a, tiles, stream);
+    case CET_RNN_GRU: return launch_split_kind<CET_RNN_GRU>(m, a, tiles, stream);
+    default: return launch_split_kind<CET_RNN_LSTM>(m, a, tiles, stream);
+  }
+}
+
+int rnn_device(const RnnModel* m) { return m->device; }
+void rnn_select(RnnModel* m, int variant) { m->variant = variant; }
+
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream) {
+  // Small batches: hidden units split over workgroups (a batch-tiled rollout of 64 sequences keeps
+  // 2 of the CUs busy for as long as one of 8192 keeps all of them busy).
+  const bool fits = split_fits(m, B, m->cus);
+  if (m->variant == 2 && !fits) return CET_ERR_TOO_LARGE;
+  if (m->variant == 2 || (m->variant == 0 && fits)) {
+    const size_t need = (SPLIT_CNT_FLOATS + (size_t)m->cus * m->layers * 2 * 256) * sizeof(float);
+    if (m->scratch_bytes < need) {  // first use: sized for the largest batch that can take this path
+      if (m->scratch) (void)hipFree(m->scratch);
+      m->scratch = nullptr;
+      m->scratch_bytes = 0;
+      CET_HIP(hipMalloc(&m->scratch, need));
+      m->scratch_bytes = need;
+    }
+    return rollout_split(m, x, out, B, seq_len, pred_len, m->scratch, stream);
+  }
   RArgs a{};
   a.wstream = m->wstream; a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b;
   a.dec_w = m->dec_w; a.dec_b = m->dec_b; a.x = x; a.out = out;

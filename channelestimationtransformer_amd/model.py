@@ -290,6 +290,7 @@ class _RecurrentBase(_DeviceWeights):
 
     def __init__(self, features, input_size, hidden_size, num_layers=2):
         super().__init__()
+        self._kernel_choice = 0
         self.num_layers = num_layers
         self.input_size = input_size
         self.hidden_size = hidden_size
@@ -311,7 +312,20 @@ class _RecurrentBase(_DeviceWeights):
                                         self.num_layers, blob.ctypes.data_as(ctypes.c_void_p),
                                         blob.size, ctypes.byref(h))
         _cabi.check(rc, "cet_rnn_create")
+        if self._kernel_choice:
+            _cabi.check(_cabi.lib().cet_rnn_select(h, self._kernel_choice), "cet_rnn_select")
         return h, None
+
+    _KERNELS = {"auto": 0, "tiled": 1, "split": 2}
+
+    def select_kernel(self, kernel):
+        """Pins the rollout kernel (tests, timing): "tiled" (a workgroup takes 32 sequences and all
+        hidden units), "split" (small batches: 16 sequences and 16 hidden units per workgroup,
+        hidden states exchanged once per layer and step) or "auto" (by batch size, the default)."""
+        self._kernel_choice = self._KERNELS[kernel]
+        for _v, h, _x in self._handles.values():
+            _cabi.check(_cabi.lib().cet_rnn_select(ctypes.c_void_p(h), self._kernel_choice), "cet_rnn_select")
+        return self
 
     def test_data(self, x, pred_len, device=None):
         """`[B, seq_len, features]` -> `[B, pred_len, features]`: seq_len teacher-forced steps,

@@ -27,7 +27,8 @@ enum {
   CET_ERR_UNSUPPORTED = 2, /* well-formed request outside what the kernels are built for */
   CET_ERR_HIP = 3,         /* a HIP runtime call failed; see cet_last_hip_error()         */
   CET_ERR_ALLOC = 4,       /* host or device allocation failed                           */
-  CET_ERR_BLOB_SIZE = 5    /* weight blob length does not match the configuration        */
+  CET_ERR_BLOB_SIZE = 5,   /* weight blob length does not match the configuration        */
+  CET_ERR_TOO_LARGE = 6    /* the batch exceeds what the requested kernel or buffer serves */
 };
 
 typedef struct cet_handle_s* cet_handle;
@@ -58,9 +59,12 @@ typedef struct cet_informer_cfg {
 } cet_informer_cfg;
 
 /* Number of fp32 values cet_informer_create expects for `cfg` (0 if cfg is unsupported).
- * Supported: n_heads = 8, 8 <= d_model <= 64, 1 <= d_ff <= 64, enc_in/dec_in in {16, 32},
- * seq_len <= 30, label_len + pred_len <= 32. The blob always has the model's own dimensions;
- * models narrower than 64 features are widened with zeros inside cet_informer_create.
+ * Supported: 1 <= n_heads <= 12 with d_model / n_heads <= 8, d_model <= 64, 1 <= d_ff <= 64,
+ * enc_in/dec_in in {16, 32}, seq_len <= 46 (48 without distilling), label_len + pred_len <= 48,
+ * at most 32 rows of concatenated encoder outputs. The blob always has the model's own dimensions;
+ * models narrower than 64 features or with fewer than 8 features per head are widened with zeros
+ * inside cet_informer_create. Models of up to 8 heads, 30 slots of history and 32 decoder rows
+ * run on both launch shapes of the kernel, larger ones on the one-wave shape only.
  * Below, d_inner = (d_model / n_heads) * n_heads (models/attn.py:126-133; 48 for d_model 54).
  *
  * Blob order (all tensors in their PyTorch layout, row-major, concatenated):
@@ -144,6 +148,15 @@ int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int 
  *   x [B, seq_len, features], out [B, pred_len, features]. */
 int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len,
                     int pred_len, void* stream);
+
+/* Pins the kernel of later rollouts of this handle (tests and timing): 0 by batch size, 1 the
+ * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
+ * kernel for small batches (16 sequences and 16 hidden units per workgroup, hidden states
+ * exchanged through a scratch buffer once per layer and step; needs ceil(B / 16) * hidden / 16
+ * workgroups resident at once, i.e. at most the device's CU count, else CET_ERR_TOO_LARGE).
+ * Not to be called while a rollout of the same handle runs on another thread. No counterpart in
+ * the reference. */
+int cet_rnn_select(cet_handle h, int kernel);
 
 /* LMMSE MIMO equalizer ---------------------------------------------------------------- */
 

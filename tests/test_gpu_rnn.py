@@ -9,18 +9,24 @@ from channelestimationtransformer_amd import blobs
 
 pytestmark = pytest.mark.gpu
 
+# The two rollout kernels: "tiled" (32 sequences and all hidden units per workgroup; large
+# batches) and "split" (16 sequences and 16 hidden units per workgroup, hidden states exchanged
+# between workgroups every layer and step; what the library picks for small batches).
+VARIANTS = ["tiled", "split"]
 
-def build(name):
+
+def build(name, variant="auto"):
     cls, _kind, F, I, H, layers = RNN_CASES[name]
     m = getattr(cet, cls)(F, I, H, layers)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sub_dict(load_npz("rnn_ckpt.npz"), name).items()})
-    return m.eval()
+    return m.eval().select_kernel(variant)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", sorted(RNN_CASES))
-def test_rollout_matches_reference(name):
+def test_rollout_matches_reference(name, variant):
     ref = load_npz("rnn_ref.npz")
-    m = build(name)
+    m = build(name, variant)
     x = ref["x"] if f"{name}/x" not in ref.files else ref[f"{name}/x"]
     xt = torch.from_numpy(x).cuda()
     for P in (5, 25):
@@ -41,7 +47,7 @@ def test_large_batch_against_checker(name, oracle):
     and agreement with the CPU checker on a sample of the sequences."""
     from channelestimationtransformer_amd import synth
     _cls, kind, F, I, H, layers = RNN_CASES[name]
-    m = build(name)
+    m = build(name, "tiled")
     noisy, _ = synth.channel_histories(8192 + 7, seed=2)
     x = cet.LoadBatch(noisy[:, :25]).cuda()
     out = m.test_data(x, 25, "cuda")
@@ -49,6 +55,13 @@ def test_large_batch_against_checker(name, oracle):
     idx = torch.arange(0, 8199, 173, device="cuda")
     sub = m.test_data(x[idx].contiguous(), 25, "cuda")
     assert torch.equal(sub, out[idx])
+    # the small-batch kernel on the same sub-batch (other summation order: close, not equal), and
+    # its refusal of a batch whose workgroups could not all be resident
+    split = m.select_kernel("split").test_data(x[idx].contiguous(), 25, "cuda")
+    assert (split - sub).abs().max() < 1e-4 * max(1.0, float(sub.abs().max()))
+    with pytest.raises(RuntimeError, match="TOO_LARGE"):
+        m.test_data(x, 25, "cuda")
+    m.select_kernel("tiled")
     blob = blobs.pack_rnn(sub_dict(load_npz("rnn_ckpt.npz"), name), kind, F, I, H, layers)
     want = oracle.rnn_rollout(kind, F, I, H, layers, blob, x[idx].cpu().numpy(), 25)
     scale = max(1.0, float(np.abs(want).max()))
@@ -59,8 +72,9 @@ def test_large_batch_against_checker(name, oracle):
     assert m.test_data(x[:0], 5, "cuda").shape == (0, 5, 16)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("name", ["LSTM", "GRU", "RNN"])
-def test_long_horizon_rollout(name, oracle):
+def test_long_horizon_rollout(name, variant, oracle):
     """pred_len 100: 124 recurrent steps, 100 of them closed-loop, against the CPU checker.
     The closed loop amplifies rounding differences (the trained LSTM by ~3x every 20 steps: two
     fp32 evaluations that agree to 1e-6 at the first prediction are 1e-3 apart at the last), so
@@ -68,7 +82,7 @@ def test_long_horizon_rollout(name, oracle):
     its input is perturbed by 1e-6 relative. The first predictions are held to a fixed bound."""
     from channelestimationtransformer_amd import synth
     _cls, kind, F, I, H, layers = RNN_CASES[name]
-    m = build(name)
+    m = build(name, variant)
     noisy, _ = synth.channel_histories(48, seed=9)
     x = cet.LoadBatch(noisy[:, :25]).cuda()
     out = m.test_data(x, 100, "cuda").cpu().numpy()
@@ -89,13 +103,14 @@ SWEEP = [(cls, F, I, H, layers) for cls in ("RNN", "GRU", "LSTM")
          for (F, I, H, layers) in ((16, 16, 128, 1), (32, 32, 256, 3), (8, 24, 128, 2), (16, 32, 256, 1))]
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("cls,F,I,H,layers", SWEEP)
-def test_random_shapes_against_checker(cls, F, I, H, layers, oracle):
+def test_random_shapes_against_checker(cls, F, I, H, layers, variant, oracle):
     """Every supported (features, input, hidden, layers) corner with random weights, a ragged
     batch and a rollout that is half teacher-forced, half closed-loop."""
     kind = {"RNN": 0, "GRU": 1, "LSTM": 2}[cls]
     torch.manual_seed(F + I + H + layers + kind)
-    m = getattr(cet, cls)(F, I, H, layers).eval()
+    m = getattr(cet, cls)(F, I, H, layers).eval().select_kernel(variant)
     sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
     rng = np.random.default_rng(H + layers)
     x = rng.standard_normal((45, 12, F)).astype(np.float32)
@@ -134,8 +149,9 @@ def test_parameter_update_then_rollout(name, oracle):
     assert torch.equal(twin.test_data(x, 3, "cuda"), after)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("cell,kind", [("GRU", 1), ("LSTM", 2), ("RNN", 0)])
-def test_nmse_against_the_reference_on_its_stored_sequences(cell, kind):
+def test_nmse_against_the_reference_on_its_stored_sequences(cell, kind, variant):
     """All 192 stored CDL-B sequences (CR_data_30/36/60) through the checkpoints the reference
     trained on them (prediciton_code/checkpoints/checkpoints_30-60_L5) and through the HPC ones:
     max-abs against the imported reference's outputs, and per-slot NMSE against slots 25..29
@@ -151,22 +167,23 @@ def test_nmse_against_the_reference_on_its_stored_sequences(cell, kind):
     for name, sd in ((f"{cell}_L5", sub_dict(v, f"{cell}_L5/sd")), (cell, sub_dict(ck, cell))):
         m = getattr(cet, cell)(16, 16, 256, 2)
         m.load_state_dict({k: torch.from_numpy(np.array(a)) for k, a in sd.items()})
-        out = m.eval().test_data(x, 5, "cuda").cpu().numpy()
+        out = m.eval().select_kernel(variant).test_data(x, 5, "cuda").cpu().numpy()
         want = v[f"{name}/pred5"]
         assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
         delta = np.abs(nmse_db(out) - nmse_db(want)).max()
         assert delta < 0.05, f"{name}: NMSE differs from the reference's by {delta} dB"
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "RNN"])
 @pytest.mark.parametrize("tag", ["fixed_direction", "best"])
-def test_more_shipped_checkpoints(cell, tag):
+def test_more_shipped_checkpoints(cell, tag, variant):
     """HPC/TrainedTransformers/{GRU,LSTM,RNN}_CDLBFixedDirection_..._uplink.pt and
     {GRU,LSTM,RNN}_best_model_params_V30_uplink.pt against the imported reference, pred_len 5 / 25."""
     v = load_npz("rnn_more.npz")
     m = getattr(cet, cell)(16, 16, 256, 2)
     m.load_state_dict({k: torch.from_numpy(np.array(a)) for k, a in sub_dict(v, f"{cell}_{tag}/sd").items()})
-    m.eval()
+    m.eval().select_kernel(variant)
     x = torch.from_numpy(v["x"]).cuda()
     for P in (5, 25):
         want = v[f"{cell}_{tag}/pred{P}"]

@@ -57,6 +57,9 @@ def test_unsupported_configurations_are_refused():
     assert L.cet_informer_blob_size(ctypes.byref(cfg)) == blobs.informer_blob_len(cfg)
     cfg.n_heads, cfg.seq_len = 8, 47  # with distilling, 46 slots is the longest history
     assert L.cet_informer_blob_size(ctypes.byref(cfg)) == 0
+    cfg.distil = 0  # without distilling the encoder outputs (40 + 20 rows) exceed the 32-row memory
+    assert L.cet_informer_blob_size(ctypes.byref(cfg)) == 0
+    cfg.distil = 1
     cfg.seq_len, cfg.label_len = 40, 43  # decoder input of 48 rows: served
     assert L.cet_informer_blob_size(ctypes.byref(cfg)) == blobs.informer_blob_len(cfg)
     rc = L.cet_rnn_create(1, 16, 16, 100, 2, dummy.ctypes.data_as(ctypes.c_void_p), 4, ctypes.byref(h))
