@@ -19,7 +19,7 @@ EXPORTS = (
     "cet_informer_blob_size", "cet_informer_create", "cet_informer_attn_size",
     "cet_informer_forward", "cet_informer_select", "cet_informer_taps_size",
     "cet_informer_forward_taps",
-    "cet_rnn_blob_size", "cet_rnn_create", "cet_rnn_rollout", "cet_rnn_select", "cet_lmmse", "cet_lmmse_direct",
+    "cet_rnn_blob_size", "cet_rnn_create", "cet_rnn_rollout", "cet_rnn_select", "cet_rnn_rollout_static", "cet_lmmse", "cet_lmmse_direct",
     "cet_lmmse_llr", "cet_lmmse_block", "cet_lmmse_block_llr", "cet_lmmse_grid", "cet_ls_nn", "cet_nmse_sums", "cet_qpsk_bit_errors",
 )
 
@@ -70,6 +70,7 @@ def lib():
     L.cet_rnn_create.argtypes = [ctypes.c_int] * 5 + [fp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.cet_rnn_rollout.argtypes = [vp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     L.cet_rnn_select.argtypes = [vp, ctypes.c_int]
+    L.cet_rnn_rollout_static.argtypes = L.cet_rnn_rollout.argtypes
     L.cet_lmmse.argtypes = [fp, fp, ctypes.c_int, ctypes.c_float, fp, fp, fp, ctypes.c_long,
                             ctypes.c_int, ctypes.c_int, vp]
     L.cet_lmmse_direct.argtypes = L.cet_lmmse.argtypes

@@ -29,6 +29,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
 void rnn_destroy(RnnModel* m);
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream);
+int rnn_rollout_static(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                       hipStream_t stream);
 void rnn_select(RnnModel* m, int variant);
 
 // A handle's weights live on the device that was current when it was created; launching from
@@ -56,7 +58,7 @@ const char* cet_strerror(int code) {
     case CET_ERR_BLOB_SIZE: return "weight blob length does not match the configuration";
     case CET_ERR_TOO_LARGE:
       return "batch too large for the requested kernel or buffer (hidden-split rollout: ceil(B / 16) * "
-             "hidden / 16 workgroups must not exceed the CU count)";
+             "hidden / 16 workgroups must not exceed the CU count, nor 256 on the static buffer)";
     default: return "unknown error code";
   }
 }
@@ -166,6 +168,17 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
   if (const int rc = check_device(h)) return rc;
   return rnn_rollout(static_cast<RnnModel*>(h->impl), x, out, B, seq_len, pred_len,
                      static_cast<hipStream_t>(stream));
+}
+
+int cet_rnn_rollout_static(cet_handle h, const float* x, float* out, int B, int seq_len, int pred_len,
+                           void* stream) {
+  if (!h || h->kind != HANDLE_RNN || B < 0 || seq_len < 1 || pred_len < 1)
+    return CET_ERR_INVALID_ARG;
+  if (B == 0) return CET_OK;
+  if (!x || !out) return CET_ERR_INVALID_ARG;
+  if (const int rc = check_device(h)) return rc;
+  return rnn_rollout_static(static_cast<RnnModel*>(h->impl), x, out, B, seq_len, pred_len,
+                            static_cast<hipStream_t>(stream));
 }
 
 int cet_rnn_select(cet_handle h, int kernel) {

@@ -798,7 +798,15 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
 // Scratch of the hidden-split kernel: arrival counters (one per tile and layer, in a block of
 // their own that is zeroed before every launch), then the exchange slices
 // [tile][layer][parity][unit group][256 floats].
+constexpr int SPLIT_MAX_WG = 256;    // workgroups the static buffer below serves (tiles x H / 16)
+constexpr int SPLIT_MAX_LAYERS = 3;
 constexpr size_t SPLIT_CNT_FLOATS = 128;  // 512 B: room for 128 counters >= 32 tiles x 3 layers
+constexpr size_t SPLIT_MAX_FLOATS = SPLIT_CNT_FLOATS + (size_t)SPLIT_MAX_WG * SPLIT_MAX_LAYERS * 2 * 256;
+
+// The buffer of the entry point that allocates nothing (cet_rnn_rollout_static): 1.5 MiB per GPU
+// the library runs on, held until the process ends. Host code never uses this name as an
+// address; rnn_create() asks the runtime for the device address once per handle.
+static __device__ __align__(256) float g_split_scratch[SPLIT_MAX_FLOATS];
 
 }  // namespace
 
@@ -817,6 +825,7 @@ struct RnnModel {
   // share it and would race.
   mutable float* scratch = nullptr;
   mutable size_t scratch_bytes = 0;
+  float* static_scratch = nullptr;  // device address of g_split_scratch on this handle's device
 };
 
 static int rnn_prepare(const RnnModel* m);  // per-device kernel attributes, defined with the launchers
@@ -941,6 +950,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   e = hipGetDevice(&m->device);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&m->cus, hipDeviceAttributeMultiprocessorCount, m->device);
+  if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void**>(&m->static_scratch), HIP_SYMBOL(g_split_scratch));
   if (e != hipSuccess) {
     rnn_destroy(m);
     return hip_fail(e);
@@ -1037,7 +1047,7 @@ static bool split_fits(const RnnModel* m, int B, int max_wg) {
 }
 
 // The hidden-split rollout on `scratch` (device, SPLIT_CNT_FLOATS + tiles * layers * 2 * H / 16 *
-// 256 floats): zeroes the counters and launches.
+// 256 floats): zeroes the counters and launches. Allocates nothing.
 static int rollout_split(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                          float* scratch, hipStream_t stream) {
   SArgs a{};
@@ -1060,6 +1070,13 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
 
 int rnn_device(const RnnModel* m) { return m->device; }
 void rnn_select(RnnModel* m, int variant) { m->variant = variant; }
+
+// The rollout on the library's static scratch buffer: no allocation on any path.
+int rnn_rollout_static(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                       hipStream_t stream) {
+  if (!split_fits(m, B, SPLIT_MAX_WG) || m->layers > SPLIT_MAX_LAYERS) return CET_ERR_TOO_LARGE;
+  return rollout_split(m, x, out, B, seq_len, pred_len, m->static_scratch, stream);
+}
 
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream) {

@@ -158,6 +158,16 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * the reference. */
 int cet_rnn_select(cet_handle h, int kernel);
 
+/* cet_rnn_rollout for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): always the hidden-split kernel, with its
+ * exchange buffer in a static device array of the library (1.5 MiB per GPU) instead of the buffer
+ * cet_rnn_rollout allocates on its first small batch. Calls hipMalloc / hipFree on no path.
+ * Limit: ceil(B / 16) * hidden / 16 <= min(256, CU count) (B <= 256 at hidden 256, B <= 512 at
+ * hidden 128), else CET_ERR_TOO_LARGE. All calls on one GPU share the array: calls that overlap in
+ * time on one GPU (other streams, other handles) race. No counterpart in the reference. */
+int cet_rnn_rollout_static(cet_handle h, const float* x, float* out, int B, int seq_len,
+                           int pred_len, void* stream);
+
 /* LMMSE MIMO equalizer ---------------------------------------------------------------- */
 
 enum {

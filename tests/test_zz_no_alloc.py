@@ -1,0 +1,43 @@
+"""The rollout entry point that allocates nothing (cet_rnn_rollout_static: the hidden-split kernel
+on the library's static device scratch array) against cet_rnn_rollout, through the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import RNN_CASES, load_npz, sub_dict
+from channelestimationtransformer_amd import _cabi, blobs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["GRU", "LSTM", "RNN", "GRU_f32_h128_l3"])
+def test_static_scratch_rollout_equals_the_allocating_entry_point(name):
+    L = _cabi.lib()
+    _cls, kind, F, I, H, layers = RNN_CASES[name]
+    blob = np.ascontiguousarray(blobs.pack_rnn(sub_dict(load_npz("rnn_ckpt.npz"), name), kind, F, I, H, layers))
+    h = ctypes.c_void_p()
+    assert L.cet_rnn_create(kind, F, I, H, layers, blob.ctypes.data_as(ctypes.c_void_p), blob.size,
+                            ctypes.byref(h)) == 0
+    try:
+        assert L.cet_rnn_select(h, 2) == 0  # the existing entry point on the same (hidden-split) kernel
+        g = torch.Generator().manual_seed(7)
+        # two calls in a row on the shared array, the second with a smaller input
+        for B, seq_len, pred_len in ((61, 25, 5), (19, 12, 3)):
+            x = (0.7 * torch.randn(B, seq_len, F, generator=g)).cuda()
+            want = torch.full((B, pred_len, F), float("nan"), device="cuda")
+            got = torch.full((B, pred_len, F), float("nan"), device="cuda")
+            assert L.cet_rnn_rollout(h, x.data_ptr(), want.data_ptr(), B, seq_len, pred_len, None) == 0
+            assert L.cet_rnn_rollout_static(h, x.data_ptr(), got.data_ptr(), B, seq_len, pred_len, None) == 0
+            torch.cuda.synchronize()
+            assert torch.isfinite(want).all()
+            assert torch.equal(got, want)  # same kernel, same arithmetic: bit for bit
+        # beyond what the static array serves: refused with its own code, nothing launched
+        B = 16 * (256 // (H // 16)) + 1
+        x = torch.zeros(B, 4, F, device="cuda")
+        out = torch.zeros(B, 2, F, device="cuda")
+        assert L.cet_rnn_rollout_static(h, x.data_ptr(), out.data_ptr(), B, 4, 2, None) == 6
+        assert b"too large" in L.cet_strerror(6)
+    finally:
+        assert L.cet_destroy(h) == 0
