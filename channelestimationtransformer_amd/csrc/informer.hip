@@ -332,13 +332,16 @@ DEV void wload(WFrag& f, const float* __restrict__ W, const Lane ln, NormParams*
   __builtin_amdgcn_sched_barrier(0);
 }
 // The same from a staged block in LDS (row stride LDW: conflict-free fragment reads).
+// Reads are issued in the order the MFMAs consume them (wmul runs its four output tiles as
+// interleaved chains: bias, then input tile 0 of every output tile, then input tile 1, ...), so
+// the matrix work starts when the first eight reads have landed, not all twenty.
 DEV void wload_lds(WFrag& f, const float* blk, const Lane ln, NormParams* norm = nullptr) {
 #pragma unroll
-  for (int mo = 0; mo < 4; ++mo) {
+  for (int mo = 0; mo < 4; ++mo) f.bv[mo] = ld4(blk + WBLK_BIAS + 16 * mo + 4 * ln.g);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) f.a[mo][mi] = ld4(blk + (16 * mo + ln.c) * LDW + 16 * mi + 4 * ln.g);
-    f.bv[mo] = ld4(blk + WBLK_BIAS + 16 * mo + 4 * ln.g);
-  }
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) f.a[mo][mi] = ld4(blk + (16 * mo + ln.c) * LDW + 16 * mi + 4 * ln.g);
   if (norm) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -355,8 +358,18 @@ DEV void next_weights(WFrag& f, Stage& st, const float* __restrict__ W, const La
                       NormParams* norm = nullptr, const float* __restrict__ norm_w = nullptr) {
   if (WG) {
     static_assert(!WG || (MO == 4 && KI == 4), "staged blocks are 64 x 64");
+#ifdef CET_PROF_FINE  // profiling build: the wait for the block and the fragment reads as phases of their own
+    PROF_MARK(ln, P_PROJ);
+    const float* blk_ = stage_acquire(st);
+    PROF_MARK(ln, P_OTHER);
+    wload_lds(f, blk_, ln, norm);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PROF_MARK(ln, P_MOVE);
+    stage_lag(st);
+#else
     wload_lds(f, stage_acquire(st), ln, norm);
     stage_lag(st);
+#endif
   } else {
     wload<MO, KI>(f, W, ln, norm, norm_w);
   }
