@@ -41,7 +41,14 @@ typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));  // for 4
 
 constexpr int DM = 64;    // d_model
 constexpr int HDIM = 8;   // features per head as the kernels lay them out (d_keys <= 8, zero padded)
-constexpr int LDW = 68;   // LDS row stride in floats (64 + 4: conflict-free fragment reads)
+#ifndef CET_LDW
+#define CET_LDW 72
+#endif
+// LDS row stride in floats. A ds_read_b128 is served in four groups of 16 lanes; lane (c, g) of a
+// fragment read addresses row c, floats 4 g .. 4 g + 3, i.e. bank group (stride / 4 * c + g) mod 16:
+// with 64 + 8 (18 c + g) every group of 16 lanes covers all 64 banks once, with 64 + 4 (17 c + g)
+// two lanes of every group collide.
+constexpr int LDW = CET_LDW;
 constexpr int MAXT = 3;   // row tiles of 16 an activation can span (sequences of up to 48 rows)
 constexpr int MAXQ = 6;   // 16-feature tiles of the widest activation (Q / K / V of 12 heads)
 constexpr int MAXROWS = 16 * MAXT;
@@ -50,7 +57,7 @@ constexpr int MAXROWS = 16 * MAXT;
 typedef f32x4 Act[MAXT][MAXQ];
 // Heads come in pairs (one 16-feature tile each): NHP = 4 serves up to 8 heads, NHP = 6 up to 12.
 // Row stride of the Q / K / V rows in LDS for NHP head pairs.
-template <int NHP> constexpr int ldq() { return 16 * NHP + 4; }
+template <int NHP> constexpr int ldq() { return 16 * NHP + (LDW - 64); }
 
 struct Dims {
   int enc_in, dec_in, c_out, seq_len, label_len, pred_len;
@@ -207,8 +214,8 @@ DEV void wave_sync() { asm volatile("" ::: "memory"); }
 // Linear(64,64) are brought into LDS once per workgroup by LDS-DMA, one product ahead of their
 // use, and every wave reads its MFMA A fragments from there: 1/8 of the vector-memory
 // instructions of the one-wave kernel, whose address path is the shared resource of a CU.
-// Staged block (floats): W[64][LDW] | bias[64] | gamma[64] | beta[64] | pad = 18 KiB.
-constexpr int WBLK = 4608;
+// Staged block (floats): W[64][LDW] | bias[64] | gamma[64] | beta[64] | pad = 19 KiB.
+constexpr int WBLK = (DM * LDW + 3 * DM + 255) / 256 * 256;  // whole 1 KiB DMA pieces
 constexpr int WBLK_BIAS = DM * LDW;
 constexpr int WBLK_NORM = WBLK_BIAS + DM;
 constexpr int WG_WAVES = 8;
@@ -1872,7 +1879,7 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     else CET_LAUNCH_WG(2, 2);
 #undef CET_LAUNCH_WG
   } else {
-    a.wave_lds_floats = 3 * R * (16 * NHP + 4);
+    a.wave_lds_floats = 3 * R * (16 * NHP + (LDW - 64));
     const size_t lds = (size_t)a.wave_lds_floats * sizeof(float);
     if (lds > 64 * 1024) return CET_ERR_UNSUPPORTED;  // cannot happen within supported()'s limits
     const dim3 grid((unsigned)B), block(64);
