@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include <atomic>
+#include <type_traits>
 
 #include "cet_internal.h"
 
@@ -37,63 +38,73 @@ namespace {
 
 constexpr int pair_index(int ns, int s, int s2) { return s * ns - s * (s + 1) / 2 + (s2 - s - 1); }
 
+// Complex values are kept as (re, im) pairs: a complex multiply-add is then two packed fp32
+// instructions (v_pk_fma_f32 with half-select / negate modifiers) instead of four scalar ones.
+// Per component the chain of fused multiply-adds is the one of the scalar statement
+//   re += ar*br; re += ai*bi; im += ar*bi; im -= ai*br        (acc += conj(a) * b)
+// so the results do not depend on which form the compiler emits.
+typedef float pair2 __attribute__((ext_vector_type(2)));
+__device__ inline pair2 fma2(pair2 a, pair2 b, pair2 c) { return __builtin_elementwise_fma(a, b, c); }
+// acc += conj(a) * b
+__device__ inline pair2 cmac_conj(pair2 acc, pair2 a, pair2 b) {
+  acc = fma2(a.xx, b, acc);
+  return fma2(a.yy, pair2{b.y, -b.x}, acc);
+}
+
 template <int NS>
 struct Gram {
   static constexpr int NP = NS * (NS - 1) / 2 > 0 ? NS * (NS - 1) / 2 : 1;
-  float diag[NS];          // sum |h_s|^2
-  float offr[NP], offi[NP];  // s < s2: sum conj(h_s) h_s2
-  float br[NS], bi[NS];    // sum conj(h_s) y
+  float diag[NS];  // sum |h_s|^2
+  pair2 off[NP];   // s < s2: sum conj(h_s) h_s2
+  pair2 b[NS];     // sum conj(h_s) y
   __device__ inline void clear() {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) diag[s] = br[s] = bi[s] = 0.f;
+    for (int s = 0; s < NS; ++s) {
+      diag[s] = 0.f;
+      b[s] = pair2{0.f, 0.f};
+    }
 #pragma unroll
-    for (int i = 0; i < NP; ++i) offr[i] = offi[i] = 0.f;
+    for (int i = 0; i < NP; ++i) off[i] = pair2{0.f, 0.f};
   }
 };
 
-// One receive antenna's contribution. WEIGHTED: row scaled by w = 1/S_r (diagonal S).
-// gram_row_h: the Gram matrix part, gram_row_b: the matched-filter part; gram_row: both.
+// One receive antenna's contribution; h = its row of H. WEIGHTED: row scaled by w = 1/S_r
+// (diagonal S). gram_row_h: the Gram matrix part, gram_row_b: the matched-filter part.
 template <int NS, bool WEIGHTED>
-__device__ inline void gram_row_h(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS], float w) {
+__device__ inline void gram_row_h(Gram<NS>& g, const pair2 (&h)[NS], float w) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const float ar = WEIGHTED ? hr[s] * w : hr[s], ai = WEIGHTED ? hi[s] * w : hi[s];
-    g.diag[s] = fmaf(ar, hr[s], g.diag[s]);
-    g.diag[s] = fmaf(ai, hi[s], g.diag[s]);
+    const pair2 a = WEIGHTED ? h[s] * w : h[s];
+    g.diag[s] = fmaf(a.x, h[s].x, g.diag[s]);
+    g.diag[s] = fmaf(a.y, h[s].y, g.diag[s]);
 #pragma unroll
     for (int s2 = s + 1; s2 < NS; ++s2) {
       const int p = pair_index(NS, s, s2);
-      g.offr[p] = fmaf(ar, hr[s2], g.offr[p]);
-      g.offr[p] = fmaf(ai, hi[s2], g.offr[p]);
-      g.offi[p] = fmaf(ar, hi[s2], g.offi[p]);
-      g.offi[p] = fmaf(-ai, hr[s2], g.offi[p]);
+      g.off[p] = cmac_conj(g.off[p], a, h[s2]);
     }
   }
 }
 template <int NS, bool WEIGHTED>
-__device__ inline void gram_row_b(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS],
-                                  float yr, float yi, float w) {
+__device__ inline void gram_row_b(Gram<NS>& g, const pair2 (&h)[NS], pair2 y, float w) {
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const float ar = WEIGHTED ? hr[s] * w : hr[s], ai = WEIGHTED ? hi[s] * w : hi[s];
-    g.br[s] = fmaf(ar, yr, g.br[s]);
-    g.br[s] = fmaf(ai, yi, g.br[s]);
-    g.bi[s] = fmaf(ar, yi, g.bi[s]);
-    g.bi[s] = fmaf(-ai, yr, g.bi[s]);
-  }
+  for (int s = 0; s < NS; ++s) g.b[s] = cmac_conj(g.b[s], WEIGHTED ? h[s] * w : h[s], y);
 }
+// The same with the row given as separate real and imaginary parts.
 template <int NS, bool WEIGHTED>
 __device__ inline void gram_row(Gram<NS>& g, const float (&hr)[NS], const float (&hi)[NS],
                                 float yr, float yi, float w) {
-  gram_row_h<NS, WEIGHTED>(g, hr, hi, w);
-  gram_row_b<NS, WEIGHTED>(g, hr, hi, yr, yi, w);
+  pair2 h[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) h[s] = pair2{hr[s], hi[s]};
+  gram_row_h<NS, WEIGHTED>(g, h, w);
+  gram_row_b<NS, WEIGHTED>(g, h, pair2{yr, yi}, w);
 }
 
 // (G + lam*I)^-1 through its Cholesky factor: W = L^-1 (lower triangular), and per stream
 // rd = 1 / d = 1 / (1 - t), ne = no_eff = t / (1 - t) with t = lam * (A^-1)_ss (file header).
 template <int NS>
 struct Factor {
-  float Wr[NS][NS], Wi[NS][NS];
+  pair2 W[NS][NS];
   float rd[NS], ne[NS];
 };
 
@@ -103,7 +114,7 @@ __device__ inline void lmmse_factor(const Gram<NS>& g, float lam, Factor<NS>& f)
   // operands the optimiser would contract depends on the surrounding code, and the kernels that
   // share this function must agree bit for bit.
 #pragma clang fp contract(off)
-  float Lr[NS][NS], Li[NS][NS], inv[NS];
+  float Lr[NS][NS], Li[NS][NS], inv[NS], Wr[NS][NS], Wi[NS][NS];
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
     float d = g.diag[j] + lam;
@@ -118,7 +129,7 @@ __device__ inline void lmmse_factor(const Gram<NS>& g, float lam, Factor<NS>& f)
 #pragma unroll
     for (int i = j + 1; i < NS; ++i) {
       const int p = pair_index(NS, j, i);
-      float sr = g.offr[p], si = -g.offi[p];  // A_ij = conj(A_ji), i > j
+      float sr = g.off[p].x, si = -g.off[p].y;  // A_ij = conj(A_ji), i > j
 #pragma unroll
       for (int k = 0; k < j; ++k) {  // s -= L_ik conj(L_jk)
         sr = fmaf(-Lr[i][k], Lr[j][k], sr);
@@ -132,20 +143,20 @@ __device__ inline void lmmse_factor(const Gram<NS>& g, float lam, Factor<NS>& f)
   }
 #pragma unroll
   for (int j = 0; j < NS; ++j) {
-    f.Wr[j][j] = inv[j];
-    f.Wi[j][j] = 0.f;
+    Wr[j][j] = inv[j];
+    Wi[j][j] = 0.f;
 #pragma unroll
     for (int i = j + 1; i < NS; ++i) {
       float sr = 0.f, si = 0.f;
 #pragma unroll
       for (int k = j; k < i; ++k) {  // s += L_ik W_kj
-        sr = fmaf(Lr[i][k], f.Wr[k][j], sr);
-        sr = fmaf(-Li[i][k], f.Wi[k][j], sr);
-        si = fmaf(Lr[i][k], f.Wi[k][j], si);
-        si = fmaf(Li[i][k], f.Wr[k][j], si);
+        sr = fmaf(Lr[i][k], Wr[k][j], sr);
+        sr = fmaf(-Li[i][k], Wi[k][j], sr);
+        si = fmaf(Lr[i][k], Wi[k][j], si);
+        si = fmaf(Li[i][k], Wr[k][j], si);
       }
-      f.Wr[i][j] = -sr * inv[i];
-      f.Wi[i][j] = -si * inv[i];
+      Wr[i][j] = -sr * inv[i];
+      Wi[i][j] = -si * inv[i];
     }
   }
 #pragma unroll
@@ -153,8 +164,9 @@ __device__ inline void lmmse_factor(const Gram<NS>& g, float lam, Factor<NS>& f)
     float a = 0.f;  // (A^-1)_ss = sum_k |W_ks|^2
 #pragma unroll
     for (int k = s; k < NS; ++k) {
-      a = fmaf(f.Wr[k][s], f.Wr[k][s], a);
-      a = fmaf(f.Wi[k][s], f.Wi[k][s], a);
+      a = fmaf(Wr[k][s], Wr[k][s], a);
+      a = fmaf(Wi[k][s], Wi[k][s], a);
+      f.W[k][s] = pair2{Wr[k][s], Wi[k][s]};
     }
     const float t = lam * a;
     f.rd[s] = __builtin_amdgcn_rcpf(1.0f - t);  // 1 ulp
@@ -162,41 +174,32 @@ __device__ inline void lmmse_factor(const Gram<NS>& g, float lam, Factor<NS>& f)
   }
 }
 
-// x_hat = diag(1/d) W^H W b for the matched-filter output b = H^H S^-1 y.
+// x_hat = diag(1/d) W^H W b for the matched-filter output b = H^H S^-1 y. Per component the
+// chains are:  u_i.re += Wr*b.re; u_i.re -= Wi*b.im; u_i.im += Wr*b.im; u_i.im += Wi*b.re  (j <= i;
+// the diagonal of W is real: its second step is left out), and likewise for z = W^H u.
 template <int NS>
-__device__ inline void lmmse_apply(const Factor<NS>& f, const float (&br)[NS], const float (&bi)[NS],
-                                   float (&xr)[NS], float (&xi)[NS]) {
+__device__ inline void lmmse_apply(const Factor<NS>& f, const pair2 (&b)[NS], pair2 (&x)[NS]) {
 #pragma clang fp contract(off)
-  float ur[NS], ui[NS];  // u = W b
+  pair2 u[NS];  // u = W b:  u_i = sum_j W_ij b_j
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
-    float sr = 0.f, si = 0.f;
+    pair2 acc{0.f, 0.f};
 #pragma unroll
     for (int j = 0; j <= i; ++j) {
-      sr = fmaf(f.Wr[i][j], br[j], sr);
-      si = fmaf(f.Wr[i][j], bi[j], si);
-      if (j < i) {  // the diagonal of W is real
-        sr = fmaf(-f.Wi[i][j], bi[j], sr);
-        si = fmaf(f.Wi[i][j], br[j], si);
-      }
+      acc = fma2(f.W[i][j].xx, b[j], acc);
+      if (j < i) acc = fma2(f.W[i][j].yy, pair2{-b[j].y, b[j].x}, acc);
     }
-    ur[i] = sr;
-    ui[i] = si;
+    u[i] = acc;
   }
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {  // z = W^H u
-    float zr = 0.f, zi = 0.f;
+  for (int s = 0; s < NS; ++s) {  // z = W^H u:  z_s = sum_k conj(W_ks) u_k
+    pair2 acc{0.f, 0.f};
 #pragma unroll
     for (int k = s; k < NS; ++k) {
-      zr = fmaf(f.Wr[k][s], ur[k], zr);
-      zi = fmaf(f.Wr[k][s], ui[k], zi);
-      if (k > s) {
-        zr = fmaf(f.Wi[k][s], ui[k], zr);
-        zi = fmaf(-f.Wi[k][s], ur[k], zi);
-      }
+      acc = fma2(f.W[k][s].xx, u[k], acc);
+      if (k > s) acc = fma2(f.W[k][s].yy, pair2{u[k].y, -u[k].x}, acc);
     }
-    xr[s] = zr * f.rd[s];
-    xi[s] = zi * f.rd[s];
+    x[s] = acc * f.rd[s];
   }
 }
 
@@ -206,15 +209,25 @@ __device__ inline void lmmse_solve(const Gram<NS>& g, float lam, float (&xr)[NS]
                                    float (&xi)[NS], float (&ne)[NS]) {
   Factor<NS> f;
   lmmse_factor<NS>(g, lam, f);
-  lmmse_apply<NS>(f, g.br, g.bi, xr, xi);
+  pair2 x[NS];
+  lmmse_apply<NS>(f, g.b, x);
 #pragma unroll
-  for (int s = 0; s < NS; ++s) ne[s] = f.ne[s];
+  for (int s = 0; s < NS; ++s) {
+    xr[s] = x[s].x;
+    xi[s] = x[s].y;
+    ne[s] = f.ne[s];
+  }
 }
 
 // Epilogue of the LLR entry point: exact ("app") log-likelihood ratios ln(P(b=1)/P(b=0)) of
 // Gray-mapped QPSK with bit 0 on the positive axis (the convention of the reference's mapper /
 // demapper pair), from the unbiased estimate and its effective noise:
 // llr = -2 sqrt(2) Re/Im(x_hat) / no_eff. Stored in place of x_hat.
+template <int NS>
+__device__ inline void to_llr(pair2 (&x)[NS], const float (&ne)[NS]) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) x[s] = x[s] * (-2.8284271247461903f * __builtin_amdgcn_rcpf(ne[s]));
+}
 template <int NS>
 __device__ inline void to_llr(float (&xr)[NS], float (&xi)[NS], const float (&ne)[NS]) {
 #pragma unroll
@@ -344,6 +357,16 @@ __device__ inline void dma16(const void* src, unsigned lds_addr_wave_uniform) {
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
       "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_addr_wave_uniform)
+      : "memory");
+}
+// The same with the streaming (non-temporal) cache policy.
+__device__ inline void dma16_nt(const void* src, unsigned lds_addr_wave_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(src), "s"(lds_addr_wave_uniform)
       : "memory");
@@ -543,13 +566,13 @@ __global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(co
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         g.diag[s] += __shfl_xor(g.diag[s], off);
-        g.br[s] += __shfl_xor(g.br[s], off);
-        g.bi[s] += __shfl_xor(g.bi[s], off);
+        g.b[s].x += __shfl_xor(g.b[s].x, off);
+        g.b[s].y += __shfl_xor(g.b[s].y, off);
       }
 #pragma unroll
       for (int i = 0; i < Gram<NS>::NP; ++i) {
-        g.offr[i] += __shfl_xor(g.offr[i], off);
-        g.offi[i] += __shfl_xor(g.offi[i], off);
+        g.off[i].x += __shfl_xor(g.off[i].x, off);
+        g.off[i].y += __shfl_xor(g.off[i].y, off);
       }
     }
     const float lam = lam_reg;
@@ -620,6 +643,64 @@ __global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(co
   }
 }
 
+// s_waitcnt vmcnt(n) for a run-time n (the count is an immediate; n above 32 waits for 32).
+template <int LO, int HI>
+__device__ inline void wait_vmcnt_range(int n) {
+  if constexpr (LO == HI) {
+    wait_vmcnt<LO>();
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (n <= MID) wait_vmcnt_range<LO, MID>(n);
+    else wait_vmcnt_range<MID + 1, HI>(n);
+  }
+}
+__device__ inline void wait_vmcnt_upto(int n) { wait_vmcnt_range<0, 32>(n < 32 ? n : 32); }
+__device__ inline void wait_vmcnt_upto16(int n) { wait_vmcnt_range<0, 16>(n < 16 ? n : 16); }
+
+// Result stores of the block-fading kernels: x_hat (or the LLRs) and no_eff of resource element
+// `re`. With two lanes per block and four streams each lane stores two streams (p = which);
+// otherwise lane p == 0 stores everything. Plain (cacheable) stores: a store instruction covers
+// 16-byte pieces of many lines, which the L2 merges with the pieces of the block's other symbols
+// before they go to HBM (nontemporal stores of such pieces halve the kernel's rate).
+template <int NS, int LPR>
+__device__ inline void store_block_results(float* __restrict__ x_hat, float* __restrict__ no_eff,
+                                           long re, int p, const pair2 (&x)[NS],
+                                           const float (&ne)[NS]) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const bool llr_mode = no_eff == nullptr;
+  if constexpr (LPR == 2 && NS == 4) {
+    const pair2 xa = p ? x[2] : x[0], xb = p ? x[3] : x[1];
+    const v2f nv = p ? v2f{ne[2], ne[3]} : v2f{ne[0], ne[1]};
+    *reinterpret_cast<v4f*>(x_hat + (re * NS + 2 * p) * 2) = v4f{xa.x, xa.y, xb.x, xb.y};
+    if (!llr_mode) *reinterpret_cast<v2f*>(no_eff + re * NS + 2 * p) = nv;
+  } else {
+    if (p != 0) return;
+    float* xd = x_hat + re * NS * 2;
+    if constexpr (NS % 2 == 0) {
+#pragma unroll
+      for (int s = 0; s < NS; s += 2) {
+        const pair2 xa = x[s], xb = x[s + 1];
+        *reinterpret_cast<v4f*>(xd + 2 * s) = v4f{xa.x, xa.y, xb.x, xb.y};
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<v2f*>(xd + 2 * s) = x[s];
+    }
+    if (!llr_mode) {
+      float* nd = no_eff + re * NS;
+      if constexpr (NS == 4) {
+        *reinterpret_cast<v4f*>(nd) = v4f{ne[0], ne[1], ne[2], ne[3]};
+      } else if constexpr (NS == 2) {
+        *reinterpret_cast<v2f*>(nd) = v2f{ne[0], ne[1]};
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) nd[s] = ne[s];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Block fading with a shared factorisation (scalar noise): one channel matrix per `hs`
 // consecutive REs. A wave owns a tile of T blocks. Its work is a sequence of equally sized
@@ -643,8 +724,14 @@ __global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(co
 #endif
 // One wave per SIMD for the large shapes: the matrices, a stage of received vectors and the
 // factor live in registers (about 300 of the 512 a lone wave may use).
+#ifndef CET_BLOCK_DMA
+#define CET_BLOCK_DMA dma16
+#endif
+#ifndef CET_BLOCK_WPS
+#define CET_BLOCK_WPS(NR, NS, LPR) 1
+#endif
 template <int NR, int NS, int LPR>
-__global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
+__global__ __launch_bounds__(64, CET_BLOCK_WPS(NR, NS, LPR)) void lmmse_block(const float* __restrict__ y,
                                                   const float* __restrict__ H, float lam,
                                                   float* __restrict__ x_hat,
                                                   float* __restrict__ no_eff, long N, int hs,
@@ -654,7 +741,11 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   constexpr int YB = NR * 8;              // bytes of y per RE
   constexpr int CH = HB / 16, CY = YB / 16;
   constexpr int H_TILE = T * HB, Y_SYM = T * YB;
+#ifdef CET_BLOCK_GS
+  constexpr int GS = CET_BLOCK_GS;
+#else
   constexpr int GS = NS * CET_BLOCK_GM;   // symbols per y stage: GS * Y_SYM == GM * H_TILE
+#endif
   constexpr int H_INSTR = H_TILE / 1024, YS_INSTR = Y_SYM / 1024;
   constexpr int RPP = NR / LPR;
   static_assert(H_TILE % 1024 == 0 && Y_SYM % 1024 == 0, "stages are whole DMA instructions");
@@ -686,7 +777,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
         const int tt = P / CH, q = P % CH;
         long blk = blk0 + tt;
         blk = blk < n_blocks ? blk : n_blocks - 1;  // tail tile: re-read the last block
-        dma16(reinterpret_cast<const char*>(H) + blk * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4),
+        CET_BLOCK_DMA(reinterpret_cast<const char*>(H) + blk * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4),
               dst + i * 1024);
       }
     } else {
@@ -700,7 +791,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
             const int tt = P / CY, q = P % CY;
             long re = (blk0 + tt) * hs + k0 + j;
             re = re < N ? re : N - 1;  // ragged end: results of these lanes are not stored
-            dma16(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
+            CET_BLOCK_DMA(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
                   dst + (j * YS_INSTR + i) * 1024);
           }
         }
@@ -714,18 +805,20 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   Factor<NS> f;
   const int swh = chunk_swizzle<CH>(t), swy = chunk_swizzle<CY>(t);
 
-  auto h_rows = [&](int rr, float (&hr)[2][NS], float (&hi)[2][NS]) {
+  // rows rr and rr + 1 of this lane's part of the matrix
+  auto h_rows = [&](int rr, pair2 (&h)[2][NS]) {
     if (NS == 1) {
       const float4 hv = hreg[rr / 2];
-      hr[0][0] = hv.x; hi[0][0] = hv.y; hr[1][0] = hv.z; hi[1][0] = hv.w;
+      h[0][0] = pair2{hv.x, hv.y};
+      h[1][0] = pair2{hv.z, hv.w};
     } else {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int j = 0; j < NS / 2; ++j) {
           const float4 hv = hreg[(rr + a) * (NS / 2) + j];
-          hr[a][2 * j] = hv.x; hi[a][2 * j] = hv.y;
-          hr[a][2 * j + 1] = hv.z; hi[a][2 * j + 1] = hv.w;
+          h[a][2 * j] = pair2{hv.x, hv.y};
+          h[a][(2 * j + 1) % NS] = pair2{hv.z, hv.w};
         }
     }
   };
@@ -767,10 +860,10 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
     g.clear();
 #pragma unroll
     for (int rr = 0; rr < RPP; rr += 2) {
-      float hr[2][NS], hi[2][NS];
-      h_rows(rr, hr, hi);
-      gram_row_h<NS, false>(g, hr[0], hi[0], 1.0f);
-      gram_row_h<NS, false>(g, hr[1], hi[1], 1.0f);
+      pair2 h[2][NS];
+      h_rows(rr, h);
+      gram_row_h<NS, false>(g, h[0], 1.0f);
+      gram_row_h<NS, false>(g, h[1], 1.0f);
     }
 #pragma unroll
     for (int off = T; off < 64; off <<= 1) {
@@ -778,80 +871,61 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
       for (int s = 0; s < NS; ++s) g.diag[s] += __shfl_xor(g.diag[s], off);
 #pragma unroll
       for (int i = 0; i < Gram<NS>::NP; ++i) {
-        g.offr[i] += __shfl_xor(g.offr[i], off);
-        g.offi[i] += __shfl_xor(g.offi[i], off);
+        g.off[i].x += __shfl_xor(g.off[i].x, off);
+        g.off[i].y += __shfl_xor(g.off[i].y, off);
       }
     }
     lmmse_factor<NS>(g, lam, f);
   };
 
+  // The matched filter takes every matrix entry as a broadcast pair (re, re) / (im, im), which a
+  // packed instruction forms by itself (half-select modifiers). Seen as common to all symbols,
+  // those pairs would be built once with moves and kept (or rebuilt with moves per symbol);
+  // passing the matrix through an empty asm per symbol makes them the symbol's own.
+  auto launder_matrix = [&]() {
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f v{hreg[k].x, hreg[k].y, hreg[k].z, hreg[k].w};
+      asm volatile("" : "+v"(v));
+      hreg[k] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
   // Store instructions per symbol when every lane is in range.
   constexpr int ST_X = (LPR == 2 && NS == 4) ? 1 : (NS % 2 == 0 ? NS / 2 : NS);
   auto equalise = [&](long tile, int k0, int nsym) {
 #pragma unroll
     for (int j = 0; j < GS; ++j) {
       if (j >= nsym) break;
+      launder_matrix();
       Gram<NS> g;
       g.clear();
 #pragma unroll
       for (int rr = 0; rr < ((CET_BLOCK_ABLATE & 2) ? 2 : RPP); rr += 2) {
         const float4 yv = yreg[j][rr / 2];
-        float hr[2][NS], hi[2][NS];
-        h_rows(rr, hr, hi);
-        gram_row_b<NS, false>(g, hr[0], hi[0], yv.x, yv.y, 1.0f);
-        gram_row_b<NS, false>(g, hr[1], hi[1], yv.z, yv.w, 1.0f);
+        pair2 h[2][NS];
+        h_rows(rr, h);
+        gram_row_b<NS, false>(g, h[0], pair2{yv.x, yv.y}, 1.0f);
+        gram_row_b<NS, false>(g, h[1], pair2{yv.z, yv.w}, 1.0f);
       }
 #pragma unroll
       for (int off = T; off < 64; off <<= 1) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          g.br[s] += __shfl_xor(g.br[s], off);
-          g.bi[s] += __shfl_xor(g.bi[s], off);
+          g.b[s].x += __shfl_xor(g.b[s].x, off);
+          g.b[s].y += __shfl_xor(g.b[s].y, off);
         }
       }
-      float xr[NS], xi[NS], ne[NS];
-      lmmse_apply<NS>(f, g.br, g.bi, xr, xi);
+      pair2 x[NS];
+      float ne[NS];
+      lmmse_apply<NS>(f, g.b, x);
 #pragma unroll
       for (int s = 0; s < NS; ++s) ne[s] = f.ne[s];
-      if (llr_mode) to_llr<NS>(xr, xi, ne);
+      if (llr_mode) to_llr<NS>(x, ne);
       const long blk = tile * T + t;
       const long re = blk * hs + k0 + j;
-      typedef float v4f __attribute__((ext_vector_type(4)));
-      typedef float v2f __attribute__((ext_vector_type(2)));
-      // plain (cacheable) stores: a store instruction covers 16-byte pieces of many lines, which
-      // the L2 merges with the pieces of the block's other symbols before they go to HBM
-      // (nontemporal stores of such pieces halve the kernel's rate)
-      // (ablation bit 0: a condition the compiler cannot fold keeps the arithmetic alive)
-      if (blk < n_blocks && re < N && (!(CET_BLOCK_ABLATE & 1) || lam < -1.0f)) {
-        if (LPR == 2 && NS == 4) {
-          constexpr int S2 = NS >= 4 ? 2 : 0, S3 = NS >= 4 ? 3 : 0;
-          const v4f xv = p ? v4f{xr[S2], xi[S2], xr[S3], xi[S3]} : v4f{xr[0], xi[0], xr[NS > 1 ? 1 : 0], xi[NS > 1 ? 1 : 0]};
-          const v2f nv = p ? v2f{ne[S2], ne[S3]} : v2f{ne[0], ne[NS > 1 ? 1 : 0]};
-          *reinterpret_cast<v4f*>(x_hat + (re * NS + 2 * p) * 2) = xv;
-          if (!llr_mode) *reinterpret_cast<v2f*>(no_eff + re * NS + 2 * p) = nv;
-        } else if (p == 0) {
-          float* xd = x_hat + re * NS * 2;
-          if (NS % 2 == 0) {
-#pragma unroll
-            for (int s = 0; s < NS; s += 2)
-              *reinterpret_cast<v4f*>(xd + 2 * s) = v4f{xr[s], xi[s], xr[s + 1], xi[s + 1]};
-          } else {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) *reinterpret_cast<v2f*>(xd + 2 * s) = v2f{xr[s], xi[s]};
-          }
-          if (!llr_mode) {
-            float* nd = no_eff + re * NS;
-            if (NS == 4) {
-              *reinterpret_cast<v4f*>(nd) =
-                  v4f{ne[0], ne[NS > 1 ? 1 : 0], ne[NS > 2 ? 2 : 0], ne[NS > 3 ? 3 : 0]};
-            } else if (NS == 2) {
-              *reinterpret_cast<v2f*>(nd) = v2f{ne[0], ne[NS > 1 ? 1 : 0]};
-            } else {
-              *nd = ne[0];
-            }
-          }
-        }
-      }
+      if (blk < n_blocks && re < N && (!(CET_BLOCK_ABLATE & 1) || lam < -1.0f))
+        store_block_results<NS, LPR>(x_hat, no_eff, re, p, x, ne);
     }
   };
 
@@ -867,25 +941,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   if (tile < n_tiles) issue(tile, 0);
   while (tile < n_tiles) {
     if (CET_BLOCK_ABLATE & 1) younger = 0;
-    switch (younger) {  // the wait count is an immediate
-      case 0: wait_vmcnt<0>(); break;
-      case 1: wait_vmcnt<1>(); break;
-      case 2: wait_vmcnt<2>(); break;
-      case 3: wait_vmcnt<3>(); break;
-      case 4: wait_vmcnt<4>(); break;
-      case 5: wait_vmcnt<5>(); break;
-      case 6: wait_vmcnt<6>(); break;
-      case 7: wait_vmcnt<7>(); break;
-      case 8: wait_vmcnt<8>(); break;
-      case 9: wait_vmcnt<9>(); break;
-      case 10: wait_vmcnt<10>(); break;
-      case 11: wait_vmcnt<11>(); break;
-      case 12: wait_vmcnt<12>(); break;
-      case 13: wait_vmcnt<13>(); break;
-      case 14: wait_vmcnt<14>(); break;
-      case 15: wait_vmcnt<15>(); break;
-      default: wait_vmcnt<16>(); break;
-    }
+    wait_vmcnt_upto16(younger);
     const int kmax = symbols_of(tile);
     const int n_here = 1 + (kmax + GS - 1) / GS;  // stages of this tile
     const int k0 = (st - 1) * GS;
@@ -913,6 +969,299 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   }
 }
 
+// The same for the shapes whose matrices fill the registers (two or more streams, 16 or more
+// matrix entries): two waves per SIMD instead of one. To fit the two-wave register budget only
+// the matrices and the factor stay in registers; the received vectors are consumed from LDS where
+// the DMA put them. The wave's LDS is a ring of NBUF buffers of one stage each; the stages of a
+// tile are the NHP parts of the matrices (part q = bytes [q, q + 1) * HB / NHP of every block)
+// followed by the received vectors, GS symbols at a time (all stages the same size). While stage
+// s is worked on, the DMA of stages s + 1 .. s + NBUF - 1 is in flight or landed.
+// Same arithmetic in the same order as lmmse_block (and the per-RE kernels): same bits.
+#ifndef CET_BLOCK2_GS
+#define CET_BLOCK2_GS(NS) ((NS) / 2)
+#endif
+#ifndef CET_BLOCK2_NBUF
+#define CET_BLOCK2_NBUF 2
+#endif
+template <int NR, int NS, int LPR>
+__global__ __launch_bounds__(64, 2) void lmmse_block2(const float* __restrict__ y,
+                                                      const float* __restrict__ H, float lam,
+                                                      float* __restrict__ x_hat,
+                                                      float* __restrict__ no_eff, long N, int hs,
+                                                      long n_blocks, long n_tiles) {
+  static_assert(NS >= 2 && NS % 2 == 0, "the matrix rows are read as pairs of streams");
+  constexpr int T = 64 / LPR;             // blocks per tile
+  constexpr int HB = NR * NS * 8;         // bytes of H per block
+  constexpr int YB = NR * 8;              // bytes of y per RE
+  constexpr int GS = CET_BLOCK2_GS(NS);   // symbols per y stage
+  constexpr int NBUF = CET_BLOCK2_NBUF;
+  constexpr int Y_SYM = T * YB;
+  constexpr int STAGE = GS * Y_SYM;       // bytes per stage
+  constexpr int NHP = T * HB / STAGE;     // matrix stages per tile
+  constexpr int CH = HB / 16, CY = YB / 16, CHP = CH / NHP;  // 16-byte chunks: block, RE, part
+  constexpr int N_INSTR = STAGE / 1024, YS_INSTR = Y_SYM / 1024;
+  constexpr int RPP = NR / LPR;
+  constexpr int HV = RPP * (NS / 2);      // float4 of matrix per lane
+  static_assert(NHP * STAGE == T * HB && CHP * NHP == CH && CHP >= 1, "the matrices are whole stages");
+  static_assert(STAGE % 1024 == 0 && Y_SYM % 1024 == 0, "stages are whole DMA instructions");
+  static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
+  static_assert(HV % CHP == 0 || CHP % HV == 0, "a lane's chunks do not straddle parts unevenly");
+
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE];
+
+  // Everything a lane derives from its index (LDS and global offsets of every chunk it touches)
+  // is loop-invariant, and hoisted out of the stage loop it would cost some 70 registers. The
+  // loop therefore re-derives it per stage from a copy of the index the optimiser cannot see
+  // through (a few integer instructions per memory instruction).
+  struct LaneId {
+    int t, p, swh, swy;
+  };
+  auto lane_id = [&](int lane) {
+    const int t = lane & (T - 1);           // block within the tile
+    const int p = LPR == 1 ? 0 : lane / T;  // which slice of the receive antennas
+    return LaneId{t, p, chunk_swizzle<CHP>(t), chunk_swizzle<CY>(t)};
+  };
+  const bool llr_mode = no_eff == nullptr;
+
+  auto symbols_of = [&](long tile) {
+    const long left = N - tile * T * hs;  // REs from the tile's first block on (> 0)
+    return left < hs ? (int)left : hs;
+  };
+
+  // Stage st of a tile into buffer b: st < NHP = part st of the matrices, NHP + g = symbols
+  // g*GS .. Always N_INSTR instructions (symbols beyond the block re-read its last one), so that
+  // the waits below can count them.
+  auto issue = [&](long tile, int st, int b, int lane) {
+    const unsigned dst = lds_address(smem) + b * STAGE;
+    const long blk0 = tile * T;
+    if (st < NHP) {
+#pragma unroll
+      for (int i = 0; i < N_INSTR; ++i) {
+        const int P = i * 64 + lane;
+        const int tt = P / CHP, q = P % CHP;
+        long blk = blk0 + tt;
+        blk = blk < n_blocks ? blk : n_blocks - 1;  // tail tile: re-read the last block
+        CET_BLOCK_DMA(reinterpret_cast<const char*>(H) + blk * HB + st * (HB / NHP) +
+                          ((q ^ chunk_swizzle<CHP>(tt)) << 4),
+                      dst + i * 1024);
+      }
+    } else {
+      const int kmax = symbols_of(tile);
+      const int k0 = (st - NHP) * GS;
+#pragma unroll
+      for (int j = 0; j < GS; ++j) {
+        const int k = k0 + j < kmax ? k0 + j : kmax - 1;
+#pragma unroll
+        for (int i = 0; i < YS_INSTR; ++i) {
+          const int P = i * 64 + lane;
+          const int tt = P / CY, q = P % CY;
+          long re = (blk0 + tt) * hs + k;
+          re = re < N ? re : N - 1;  // ragged end: results of these lanes are not stored
+          CET_BLOCK_DMA(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
+                        dst + (j * YS_INSTR + i) * 1024);
+        }
+      }
+    }
+  };
+
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f hreg[HV];  // this lane's rows of its block's matrix, for the whole tile
+  Factor<NS> f;
+
+  // rows rr and rr + 1 of this lane's part of the matrix
+  auto h_rows = [&](int rr, pair2 (&h)[2][NS]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int j = 0; j < NS / 2; ++j) {
+        const v4f hv = hreg[(rr + a) * (NS / 2) + j];
+        h[a][2 * j] = pair2{hv.x, hv.y};
+        h[a][2 * j + 1] = pair2{hv.z, hv.w};
+      }
+  };
+
+  // Copies this lane's chunks of matrix part `part` from buffer b. Chunk k of the lane is chunk
+  // p * HV + k of the block (the lane's rows are contiguous).
+  auto copy_part = [&](int part, int b, const LaneId id) {
+    const char* hsrc = smem + b * STAGE + id.t * (HB / NHP);
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      const int c = id.p * HV + k;  // p is 0 or 1; HV and CHP are powers of two
+      if (c / CHP == part)
+        hreg[k] = *reinterpret_cast<const v4f*>(hsrc + (((c % CHP) ^ id.swh) << 4));
+    }
+  };
+
+  auto factorise = [&]() {
+    Gram<NS> g;
+    g.clear();
+#pragma unroll
+    for (int rr = 0; rr < RPP; rr += 2) {
+      pair2 h[2][NS];
+      h_rows(rr, h);
+      gram_row_h<NS, false>(g, h[0], 1.0f);
+      gram_row_h<NS, false>(g, h[1], 1.0f);
+    }
+#pragma unroll
+    for (int off = T; off < 64; off <<= 1) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) g.diag[s] += __shfl_xor(g.diag[s], off);
+#pragma unroll
+      for (int i = 0; i < Gram<NS>::NP; ++i) {
+        g.off[i].x += __shfl_xor(g.off[i].x, off);
+        g.off[i].y += __shfl_xor(g.off[i].y, off);
+      }
+    }
+    lmmse_factor<NS>(g, lam, f);
+  };
+
+  // The matched filter takes every matrix entry as a broadcast pair (re, re) / (im, im), which a
+  // packed instruction forms by itself (half-select modifiers). Seen as common to all symbols,
+  // those pairs would be built once with moves and kept (or rebuilt with moves per symbol);
+  // passing the matrix through an empty asm per symbol makes them the symbol's own.
+  auto launder_matrix = [&]() {
+#pragma unroll
+    for (int k = 0; k < HV; ++k) {
+      v4f v = hreg[k];
+      asm volatile("" : "+v"(v));
+      hreg[k] = v;
+    }
+  };
+  constexpr int ST_X = (LPR == 2 && NS == 4) ? 1 : NS / 2;  // x_hat store instructions per symbol
+  auto equalise = [&](long tile, int k0, int nsym, int b, const LaneId id) {
+    const int t = id.t, p = id.p, swy = id.swy;
+#pragma unroll 1
+    for (int j = 0; j < nsym; ++j) {
+      launder_matrix();
+      const char* ysrc = smem + b * STAGE + j * Y_SYM + t * YB;
+      v4f yv[RPP / 2];
+#pragma unroll
+      for (int rr = 0; rr < RPP; rr += 2)
+        yv[rr / 2] = *reinterpret_cast<const v4f*>(ysrc + ((((p * RPP + rr) >> 1) ^ swy) << 4));
+      Gram<NS> g;
+      g.clear();
+#pragma unroll
+      for (int rr = 0; rr < RPP; rr += 2) {
+        pair2 h[2][NS];
+        h_rows(rr, h);
+        gram_row_b<NS, false>(g, h[0], pair2{yv[rr / 2].x, yv[rr / 2].y}, 1.0f);
+        gram_row_b<NS, false>(g, h[1], pair2{yv[rr / 2].z, yv[rr / 2].w}, 1.0f);
+      }
+#pragma unroll
+      for (int off = T; off < 64; off <<= 1) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          g.b[s].x += __shfl_xor(g.b[s].x, off);
+          g.b[s].y += __shfl_xor(g.b[s].y, off);
+        }
+      }
+      pair2 x[NS];
+      float ne[NS];
+      lmmse_apply<NS>(f, g.b, x);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ne[s] = f.ne[s];
+      if (llr_mode) to_llr<NS>(x, ne);
+      const long blk = tile * T + t;
+      const long re = blk * hs + k0 + j;
+      if (blk < n_blocks && re < N && (!(CET_BLOCK_ABLATE & 1) || lam < -1.0f))
+        store_block_results<NS, LPR>(x_hat, no_eff, re, p, x, ne);
+    }
+  };
+
+  // Stage pipeline. vmcnt retires vector-memory instructions in issue order. Per stage s the
+  // wave issues, in this order: DMA(s + NBUF - 1) (N_INSTR instructions), then the stores of
+  // stage s. Younger than DMA(s) at the time stage s waits for it are therefore the DMAs of
+  // stages s + 1 .. s + NBUF - 2 that exist and the stores of the NBUF - 1 stages before s.
+  // `stores[i]` holds a lower bound of the store instructions of the i-th last stage: exact for
+  // a tile whose T blocks are all complete, 1 otherwise (a store whose lanes are all out of range
+  // is branched over, but the tile's first block and a stage's first symbol always exist), 0
+  // for a matrix stage.
+  struct Pos {
+    long tile;
+    int st;
+  };
+  auto next_pos = [&](Pos c) {
+    const int n_here = NHP + (symbols_of(c.tile) + GS - 1) / GS;  // stages of the tile
+    Pos n{c.tile, c.st + 1};
+    if (n.st >= n_here) n = Pos{c.tile + (long)gridDim.x, 0};
+    return n;
+  };
+  Pos cur{(long)blockIdx.x, 0};  // the stage worked on
+  Pos req = cur;                 // the next stage to request
+  int breq = 0, b = 0;           // their buffers
+  int ahead = 0;                 // requested stages beyond the current one
+  int stores[NBUF - 1];
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) stores[i] = 0;
+  // prologue: stages 0 .. NBUF - 2
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) {
+    if (req.tile < n_tiles) {
+      issue(req.tile, req.st, breq, threadIdx.x);
+      req = next_pos(req);
+      breq = breq + 1 == NBUF ? 0 : breq + 1;
+      ++ahead;
+    }
+  }
+  --ahead;  // the first of them is the current stage
+  while (cur.tile < n_tiles) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));  // see lane_id
+    const LaneId id = lane_id(lane);
+    // the buffer of the stage before this one is free (its reads have returned): request into it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (req.tile < n_tiles) {
+      issue(req.tile, req.st, breq, lane);
+      req = next_pos(req);
+      breq = breq + 1 == NBUF ? 0 : breq + 1;
+      ++ahead;
+    }
+    int younger = ahead * N_INSTR;
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) younger += stores[i];
+    if (CET_BLOCK_ABLATE & 1) younger = ahead * N_INSTR;
+    wait_vmcnt_upto(younger);
+    int stored = 0;
+    if (cur.st < NHP) {
+#pragma unroll
+      for (int q = 0; q < NHP; ++q)
+        if (cur.st == q) copy_part(q, b, id);
+      if (cur.st == NHP - 1) factorise();
+    } else {
+      const int kmax = symbols_of(cur.tile);
+      const int k0 = (cur.st - NHP) * GS;
+      const int nsym = kmax - k0 < GS ? kmax - k0 : GS;
+      equalise(cur.tile, k0, nsym, b, id);
+      const bool full_tile = (cur.tile * T + T) * hs <= N;
+      stored = full_tile ? nsym * (ST_X + (llr_mode ? 0 : 1)) : 1;
+    }
+#pragma unroll
+    for (int i = NBUF - 2; i > 0; --i) stores[i] = stores[i - 1];
+    stores[0] = stored;
+    cur = next_pos(cur);
+    b = b + 1 == NBUF ? 0 : b + 1;
+    --ahead;
+  }
+}
+
+// Which block-fading kernel serves a shape: the two-wave kernel where the one-wave kernel's
+// registers (matrices + a stage of received vectors) keep it to one wave per SIMD.
+#ifndef CET_BLOCK2
+#define CET_BLOCK2(NR, NS) ((NS) >= 2 && (NR) * (NS) >= 16)
+#endif
+template <int NR, int NS, int LPR>
+struct BlockKernel {
+  static constexpr bool two_wave = CET_BLOCK2(NR, NS);
+  template <bool B = two_wave>
+  static typename std::enable_if<B, void (*)(const float*, const float*, float, float*, float*, long,
+                                             int, long, long)>::type
+  get() { return &lmmse_block2<NR, NS, LPR>; }
+  template <bool B = two_wave>
+  static typename std::enable_if<!B, void (*)(const float*, const float*, float, float*, float*, long,
+                                              int, long, long)>::type
+  get() { return &lmmse_block<NR, NS, LPR>; }
+};
+
 template <int NR, int NS, int LPR>
 int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, float* no_eff,
                  long N, int hshare, hipStream_t stream) {
@@ -922,20 +1271,20 @@ int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, 
   int dev = 0, cus = 256;
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const auto kernel = BlockKernel<NR, NS, LPR>::get();
   // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per CU
   static std::atomic<int> per_cu_cached{0};  // a property of the kernel's registers and LDS
   int per_cu = per_cu_cached.load(std::memory_order_relaxed);
   if (!per_cu) {
     int nb = 0;
-    CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &nb, reinterpret_cast<const void*>(&lmmse_block<NR, NS, LPR>), 64, 0));
+    CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 64, 0));
     per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
     per_cu_cached.store(per_cu, std::memory_order_relaxed);
   }
   long grid = (long)cus * per_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((lmmse_block<NR, NS, LPR>), dim3((unsigned)grid), dim3(64), 0, stream, y, H,
-                     no_scalar, x_hat, no_eff, N, hshare, n_blocks, n_tiles);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64), 0, stream, y, H, no_scalar, x_hat,
+                     no_eff, N, hshare, n_blocks, n_tiles);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
