@@ -29,7 +29,6 @@
 #include <cstdlib>
 
 #include <atomic>
-#include <type_traits>
 
 #include "cet_internal.h"
 
@@ -361,16 +360,6 @@ __device__ inline void dma16(const void* src, unsigned lds_addr_wave_uniform) {
       : "v"(src), "s"(lds_addr_wave_uniform)
       : "memory");
 }
-// The same with the streaming (non-temporal) cache policy.
-__device__ inline void dma16_nt(const void* src, unsigned lds_addr_wave_uniform) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_addr_wave_uniform)
-      : "memory");
-}
 __device__ inline void dma4(const void* src, unsigned lds_addr_wave_uniform) {
   unsigned keep;
   asm volatile(
@@ -643,7 +632,7 @@ __global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(co
   }
 }
 
-// s_waitcnt vmcnt(n) for a run-time n (the count is an immediate; n above 32 waits for 32).
+// s_waitcnt vmcnt(n) for a run-time n (the count is an immediate; n above 16 waits for 16).
 template <int LO, int HI>
 __device__ inline void wait_vmcnt_range(int n) {
   if constexpr (LO == HI) {
@@ -654,7 +643,6 @@ __device__ inline void wait_vmcnt_range(int n) {
     else wait_vmcnt_range<MID + 1, HI>(n);
   }
 }
-__device__ inline void wait_vmcnt_upto(int n) { wait_vmcnt_range<0, 32>(n < 32 ? n : 32); }
 __device__ inline void wait_vmcnt_upto16(int n) { wait_vmcnt_range<0, 16>(n < 16 ? n : 16); }
 
 // Result stores of the block-fading kernels: x_hat (or the LLRs) and no_eff of resource element
@@ -723,15 +711,15 @@ __device__ inline void store_block_results(float* __restrict__ x_hat, float* __r
 #define CET_BLOCK_GM 1
 #endif
 // One wave per SIMD for the large shapes: the matrices, a stage of received vectors and the
-// factor live in registers (about 300 of the 512 a lone wave may use).
-#ifndef CET_BLOCK_DMA
-#define CET_BLOCK_DMA dma16
-#endif
-#ifndef CET_BLOCK_WPS
-#define CET_BLOCK_WPS(NR, NS, LPR) 1
-#endif
+// factor live in registers (about 300 of the 512 a lone wave may use). A variant for two waves
+// per SIMD (only the matrices and the factor in registers, the received vectors consumed from a
+// ring of two to four LDS buffers) was slower on every shape (16x4: 0.48 against 0.43 ms per
+// 8.4 M REs; it wrote 69 instead of 58 B/RE because the pieces of a 128-byte line arrive over two
+// stages), as was the streaming cache policy on the DMA: neither the vector unit (the packed
+// arithmetic removed a third of its instructions for 3 % of the time) nor the bytes in flight
+// bound this kernel; with and without its stores it moves 4.0 to 4.3 TB/s.
 template <int NR, int NS, int LPR>
-__global__ __launch_bounds__(64, CET_BLOCK_WPS(NR, NS, LPR)) void lmmse_block(const float* __restrict__ y,
+__global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
                                                   const float* __restrict__ H, float lam,
                                                   float* __restrict__ x_hat,
                                                   float* __restrict__ no_eff, long N, int hs,
@@ -741,11 +729,7 @@ __global__ __launch_bounds__(64, CET_BLOCK_WPS(NR, NS, LPR)) void lmmse_block(co
   constexpr int YB = NR * 8;              // bytes of y per RE
   constexpr int CH = HB / 16, CY = YB / 16;
   constexpr int H_TILE = T * HB, Y_SYM = T * YB;
-#ifdef CET_BLOCK_GS
-  constexpr int GS = CET_BLOCK_GS;
-#else
   constexpr int GS = NS * CET_BLOCK_GM;   // symbols per y stage: GS * Y_SYM == GM * H_TILE
-#endif
   constexpr int H_INSTR = H_TILE / 1024, YS_INSTR = Y_SYM / 1024;
   constexpr int RPP = NR / LPR;
   static_assert(H_TILE % 1024 == 0 && Y_SYM % 1024 == 0, "stages are whole DMA instructions");
@@ -777,7 +761,7 @@ __global__ __launch_bounds__(64, CET_BLOCK_WPS(NR, NS, LPR)) void lmmse_block(co
         const int tt = P / CH, q = P % CH;
         long blk = blk0 + tt;
         blk = blk < n_blocks ? blk : n_blocks - 1;  // tail tile: re-read the last block
-        CET_BLOCK_DMA(reinterpret_cast<const char*>(H) + blk * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4),
+        dma16(reinterpret_cast<const char*>(H) + blk * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4),
               dst + i * 1024);
       }
     } else {
@@ -791,7 +775,7 @@ __global__ __launch_bounds__(64, CET_BLOCK_WPS(NR, NS, LPR)) void lmmse_block(co
             const int tt = P / CY, q = P % CY;
             long re = (blk0 + tt) * hs + k0 + j;
             re = re < N ? re : N - 1;  // ragged end: results of these lanes are not stored
-            CET_BLOCK_DMA(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
+            dma16(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
                   dst + (j * YS_INSTR + i) * 1024);
           }
         }
@@ -969,299 +953,6 @@ __global__ __launch_bounds__(64, CET_BLOCK_WPS(NR, NS, LPR)) void lmmse_block(co
   }
 }
 
-// The same for the shapes whose matrices fill the registers (two or more streams, 16 or more
-// matrix entries): two waves per SIMD instead of one. To fit the two-wave register budget only
-// the matrices and the factor stay in registers; the received vectors are consumed from LDS where
-// the DMA put them. The wave's LDS is a ring of NBUF buffers of one stage each; the stages of a
-// tile are the NHP parts of the matrices (part q = bytes [q, q + 1) * HB / NHP of every block)
-// followed by the received vectors, GS symbols at a time (all stages the same size). While stage
-// s is worked on, the DMA of stages s + 1 .. s + NBUF - 1 is in flight or landed.
-// Same arithmetic in the same order as lmmse_block (and the per-RE kernels): same bits.
-#ifndef CET_BLOCK2_GS
-#define CET_BLOCK2_GS(NS) ((NS) / 2)
-#endif
-#ifndef CET_BLOCK2_NBUF
-#define CET_BLOCK2_NBUF 2
-#endif
-template <int NR, int NS, int LPR>
-__global__ __launch_bounds__(64, 2) void lmmse_block2(const float* __restrict__ y,
-                                                      const float* __restrict__ H, float lam,
-                                                      float* __restrict__ x_hat,
-                                                      float* __restrict__ no_eff, long N, int hs,
-                                                      long n_blocks, long n_tiles) {
-  static_assert(NS >= 2 && NS % 2 == 0, "the matrix rows are read as pairs of streams");
-  constexpr int T = 64 / LPR;             // blocks per tile
-  constexpr int HB = NR * NS * 8;         // bytes of H per block
-  constexpr int YB = NR * 8;              // bytes of y per RE
-  constexpr int GS = CET_BLOCK2_GS(NS);   // symbols per y stage
-  constexpr int NBUF = CET_BLOCK2_NBUF;
-  constexpr int Y_SYM = T * YB;
-  constexpr int STAGE = GS * Y_SYM;       // bytes per stage
-  constexpr int NHP = T * HB / STAGE;     // matrix stages per tile
-  constexpr int CH = HB / 16, CY = YB / 16, CHP = CH / NHP;  // 16-byte chunks: block, RE, part
-  constexpr int N_INSTR = STAGE / 1024, YS_INSTR = Y_SYM / 1024;
-  constexpr int RPP = NR / LPR;
-  constexpr int HV = RPP * (NS / 2);      // float4 of matrix per lane
-  static_assert(NHP * STAGE == T * HB && CHP * NHP == CH && CHP >= 1, "the matrices are whole stages");
-  static_assert(STAGE % 1024 == 0 && Y_SYM % 1024 == 0, "stages are whole DMA instructions");
-  static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
-  static_assert(HV % CHP == 0 || CHP % HV == 0, "a lane's chunks do not straddle parts unevenly");
-
-  __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE];
-
-  // Everything a lane derives from its index (LDS and global offsets of every chunk it touches)
-  // is loop-invariant, and hoisted out of the stage loop it would cost some 70 registers. The
-  // loop therefore re-derives it per stage from a copy of the index the optimiser cannot see
-  // through (a few integer instructions per memory instruction).
-  struct LaneId {
-    int t, p, swh, swy;
-  };
-  auto lane_id = [&](int lane) {
-    const int t = lane & (T - 1);           // block within the tile
-    const int p = LPR == 1 ? 0 : lane / T;  // which slice of the receive antennas
-    return LaneId{t, p, chunk_swizzle<CHP>(t), chunk_swizzle<CY>(t)};
-  };
-  const bool llr_mode = no_eff == nullptr;
-
-  auto symbols_of = [&](long tile) {
-    const long left = N - tile * T * hs;  // REs from the tile's first block on (> 0)
-    return left < hs ? (int)left : hs;
-  };
-
-  // Stage st of a tile into buffer b: st < NHP = part st of the matrices, NHP + g = symbols
-  // g*GS .. Always N_INSTR instructions (symbols beyond the block re-read its last one), so that
-  // the waits below can count them.
-  auto issue = [&](long tile, int st, int b, int lane) {
-    const unsigned dst = lds_address(smem) + b * STAGE;
-    const long blk0 = tile * T;
-    if (st < NHP) {
-#pragma unroll
-      for (int i = 0; i < N_INSTR; ++i) {
-        const int P = i * 64 + lane;
-        const int tt = P / CHP, q = P % CHP;
-        long blk = blk0 + tt;
-        blk = blk < n_blocks ? blk : n_blocks - 1;  // tail tile: re-read the last block
-        CET_BLOCK_DMA(reinterpret_cast<const char*>(H) + blk * HB + st * (HB / NHP) +
-                          ((q ^ chunk_swizzle<CHP>(tt)) << 4),
-                      dst + i * 1024);
-      }
-    } else {
-      const int kmax = symbols_of(tile);
-      const int k0 = (st - NHP) * GS;
-#pragma unroll
-      for (int j = 0; j < GS; ++j) {
-        const int k = k0 + j < kmax ? k0 + j : kmax - 1;
-#pragma unroll
-        for (int i = 0; i < YS_INSTR; ++i) {
-          const int P = i * 64 + lane;
-          const int tt = P / CY, q = P % CY;
-          long re = (blk0 + tt) * hs + k;
-          re = re < N ? re : N - 1;  // ragged end: results of these lanes are not stored
-          CET_BLOCK_DMA(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
-                        dst + (j * YS_INSTR + i) * 1024);
-        }
-      }
-    }
-  };
-
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  v4f hreg[HV];  // this lane's rows of its block's matrix, for the whole tile
-  Factor<NS> f;
-
-  // rows rr and rr + 1 of this lane's part of the matrix
-  auto h_rows = [&](int rr, pair2 (&h)[2][NS]) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int j = 0; j < NS / 2; ++j) {
-        const v4f hv = hreg[(rr + a) * (NS / 2) + j];
-        h[a][2 * j] = pair2{hv.x, hv.y};
-        h[a][2 * j + 1] = pair2{hv.z, hv.w};
-      }
-  };
-
-  // Copies this lane's chunks of matrix part `part` from buffer b. Chunk k of the lane is chunk
-  // p * HV + k of the block (the lane's rows are contiguous).
-  auto copy_part = [&](int part, int b, const LaneId id) {
-    const char* hsrc = smem + b * STAGE + id.t * (HB / NHP);
-#pragma unroll
-    for (int k = 0; k < HV; ++k) {
-      const int c = id.p * HV + k;  // p is 0 or 1; HV and CHP are powers of two
-      if (c / CHP == part)
-        hreg[k] = *reinterpret_cast<const v4f*>(hsrc + (((c % CHP) ^ id.swh) << 4));
-    }
-  };
-
-  auto factorise = [&]() {
-    Gram<NS> g;
-    g.clear();
-#pragma unroll
-    for (int rr = 0; rr < RPP; rr += 2) {
-      pair2 h[2][NS];
-      h_rows(rr, h);
-      gram_row_h<NS, false>(g, h[0], 1.0f);
-      gram_row_h<NS, false>(g, h[1], 1.0f);
-    }
-#pragma unroll
-    for (int off = T; off < 64; off <<= 1) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s) g.diag[s] += __shfl_xor(g.diag[s], off);
-#pragma unroll
-      for (int i = 0; i < Gram<NS>::NP; ++i) {
-        g.off[i].x += __shfl_xor(g.off[i].x, off);
-        g.off[i].y += __shfl_xor(g.off[i].y, off);
-      }
-    }
-    lmmse_factor<NS>(g, lam, f);
-  };
-
-  // The matched filter takes every matrix entry as a broadcast pair (re, re) / (im, im), which a
-  // packed instruction forms by itself (half-select modifiers). Seen as common to all symbols,
-  // those pairs would be built once with moves and kept (or rebuilt with moves per symbol);
-  // passing the matrix through an empty asm per symbol makes them the symbol's own.
-  auto launder_matrix = [&]() {
-#pragma unroll
-    for (int k = 0; k < HV; ++k) {
-      v4f v = hreg[k];
-      asm volatile("" : "+v"(v));
-      hreg[k] = v;
-    }
-  };
-  constexpr int ST_X = (LPR == 2 && NS == 4) ? 1 : NS / 2;  // x_hat store instructions per symbol
-  auto equalise = [&](long tile, int k0, int nsym, int b, const LaneId id) {
-    const int t = id.t, p = id.p, swy = id.swy;
-#pragma unroll 1
-    for (int j = 0; j < nsym; ++j) {
-      launder_matrix();
-      const char* ysrc = smem + b * STAGE + j * Y_SYM + t * YB;
-      v4f yv[RPP / 2];
-#pragma unroll
-      for (int rr = 0; rr < RPP; rr += 2)
-        yv[rr / 2] = *reinterpret_cast<const v4f*>(ysrc + ((((p * RPP + rr) >> 1) ^ swy) << 4));
-      Gram<NS> g;
-      g.clear();
-#pragma unroll
-      for (int rr = 0; rr < RPP; rr += 2) {
-        pair2 h[2][NS];
-        h_rows(rr, h);
-        gram_row_b<NS, false>(g, h[0], pair2{yv[rr / 2].x, yv[rr / 2].y}, 1.0f);
-        gram_row_b<NS, false>(g, h[1], pair2{yv[rr / 2].z, yv[rr / 2].w}, 1.0f);
-      }
-#pragma unroll
-      for (int off = T; off < 64; off <<= 1) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          g.b[s].x += __shfl_xor(g.b[s].x, off);
-          g.b[s].y += __shfl_xor(g.b[s].y, off);
-        }
-      }
-      pair2 x[NS];
-      float ne[NS];
-      lmmse_apply<NS>(f, g.b, x);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) ne[s] = f.ne[s];
-      if (llr_mode) to_llr<NS>(x, ne);
-      const long blk = tile * T + t;
-      const long re = blk * hs + k0 + j;
-      if (blk < n_blocks && re < N && (!(CET_BLOCK_ABLATE & 1) || lam < -1.0f))
-        store_block_results<NS, LPR>(x_hat, no_eff, re, p, x, ne);
-    }
-  };
-
-  // Stage pipeline. vmcnt retires vector-memory instructions in issue order. Per stage s the
-  // wave issues, in this order: DMA(s + NBUF - 1) (N_INSTR instructions), then the stores of
-  // stage s. Younger than DMA(s) at the time stage s waits for it are therefore the DMAs of
-  // stages s + 1 .. s + NBUF - 2 that exist and the stores of the NBUF - 1 stages before s.
-  // `stores[i]` holds a lower bound of the store instructions of the i-th last stage: exact for
-  // a tile whose T blocks are all complete, 1 otherwise (a store whose lanes are all out of range
-  // is branched over, but the tile's first block and a stage's first symbol always exist), 0
-  // for a matrix stage.
-  struct Pos {
-    long tile;
-    int st;
-  };
-  auto next_pos = [&](Pos c) {
-    const int n_here = NHP + (symbols_of(c.tile) + GS - 1) / GS;  // stages of the tile
-    Pos n{c.tile, c.st + 1};
-    if (n.st >= n_here) n = Pos{c.tile + (long)gridDim.x, 0};
-    return n;
-  };
-  Pos cur{(long)blockIdx.x, 0};  // the stage worked on
-  Pos req = cur;                 // the next stage to request
-  int breq = 0, b = 0;           // their buffers
-  int ahead = 0;                 // requested stages beyond the current one
-  int stores[NBUF - 1];
-#pragma unroll
-  for (int i = 0; i < NBUF - 1; ++i) stores[i] = 0;
-  // prologue: stages 0 .. NBUF - 2
-#pragma unroll
-  for (int i = 0; i < NBUF - 1; ++i) {
-    if (req.tile < n_tiles) {
-      issue(req.tile, req.st, breq, threadIdx.x);
-      req = next_pos(req);
-      breq = breq + 1 == NBUF ? 0 : breq + 1;
-      ++ahead;
-    }
-  }
-  --ahead;  // the first of them is the current stage
-  while (cur.tile < n_tiles) {
-    int lane = threadIdx.x;
-    asm volatile("" : "+v"(lane));  // see lane_id
-    const LaneId id = lane_id(lane);
-    // the buffer of the stage before this one is free (its reads have returned): request into it
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (req.tile < n_tiles) {
-      issue(req.tile, req.st, breq, lane);
-      req = next_pos(req);
-      breq = breq + 1 == NBUF ? 0 : breq + 1;
-      ++ahead;
-    }
-    int younger = ahead * N_INSTR;
-#pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i) younger += stores[i];
-    if (CET_BLOCK_ABLATE & 1) younger = ahead * N_INSTR;
-    wait_vmcnt_upto(younger);
-    int stored = 0;
-    if (cur.st < NHP) {
-#pragma unroll
-      for (int q = 0; q < NHP; ++q)
-        if (cur.st == q) copy_part(q, b, id);
-      if (cur.st == NHP - 1) factorise();
-    } else {
-      const int kmax = symbols_of(cur.tile);
-      const int k0 = (cur.st - NHP) * GS;
-      const int nsym = kmax - k0 < GS ? kmax - k0 : GS;
-      equalise(cur.tile, k0, nsym, b, id);
-      const bool full_tile = (cur.tile * T + T) * hs <= N;
-      stored = full_tile ? nsym * (ST_X + (llr_mode ? 0 : 1)) : 1;
-    }
-#pragma unroll
-    for (int i = NBUF - 2; i > 0; --i) stores[i] = stores[i - 1];
-    stores[0] = stored;
-    cur = next_pos(cur);
-    b = b + 1 == NBUF ? 0 : b + 1;
-    --ahead;
-  }
-}
-
-// Which block-fading kernel serves a shape: the two-wave kernel where the one-wave kernel's
-// registers (matrices + a stage of received vectors) keep it to one wave per SIMD.
-#ifndef CET_BLOCK2
-#define CET_BLOCK2(NR, NS) ((NS) >= 2 && (NR) * (NS) >= 16)
-#endif
-template <int NR, int NS, int LPR>
-struct BlockKernel {
-  static constexpr bool two_wave = CET_BLOCK2(NR, NS);
-  template <bool B = two_wave>
-  static typename std::enable_if<B, void (*)(const float*, const float*, float, float*, float*, long,
-                                             int, long, long)>::type
-  get() { return &lmmse_block2<NR, NS, LPR>; }
-  template <bool B = two_wave>
-  static typename std::enable_if<!B, void (*)(const float*, const float*, float, float*, float*, long,
-                                              int, long, long)>::type
-  get() { return &lmmse_block<NR, NS, LPR>; }
-};
-
 template <int NR, int NS, int LPR>
 int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, float* no_eff,
                  long N, int hshare, hipStream_t stream) {
@@ -1271,7 +962,7 @@ int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, 
   int dev = 0, cus = 256;
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const auto kernel = BlockKernel<NR, NS, LPR>::get();
+  const auto kernel = &lmmse_block<NR, NS, LPR>;
   // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per CU
   static std::atomic<int> per_cu_cached{0};  // a property of the kernel's registers and LDS
   int per_cu = per_cu_cached.load(std::memory_order_relaxed);
