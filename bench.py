@@ -499,6 +499,23 @@ def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
     extra["informer_with_host_transfers"] = {
         "predictions_per_s": B / dh, "step_ms": dh * 1e3,
         "note": "pinned host input (x_enc, x_dec) -> device -> forward -> prediction to pinned host"}
+    # the same with three batches in flight on three streams (HostPipeline): upload of batch i + 1
+    # and download of batch i - 1 behind the forward of batch i
+    from channelestimationtransformer_amd import HostPipeline
+    pipe = HostPipeline(lambda a, b: model(a, b), [tuple(x.shape), tuple(xd.shape)], (B, 5, 16), device=dev)
+    for sl in pipe.slots:
+        sl.host_in[0].copy_(xh)
+        sl.host_in[1].copy_(xdh)
+    n_pipe = max(20, 2 * args.steps)
+    pipe.run(10, lambda i, h: None, lambda i, o: None)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    pipe.run(n_pipe, lambda i, h: None, lambda i, o: None)
+    torch.cuda.synchronize(dev)
+    dp = (time.perf_counter() - t0) / n_pipe
+    extra["informer_with_host_transfers_pipelined"] = {
+        "predictions_per_s": B / dp, "step_ms": dp * 1e3, "batches": n_pipe,
+        "note": "the same from / to pinned host buffers through HostPipeline (3 batches in flight, wall clock per batch)"}
 
     # ---- LMMSE: the stated size of the metric's second half, then the other shapes -------------
     one = Ctx(dev, 0, 1, False)
