@@ -38,6 +38,27 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # Algorithmic work / bytes per unit (dense contractions only for the FLOP figures).
 INFORMER_FLOP = 8.897e6          # per prediction, default configuration
+
+
+def informer_flop(seq, label, pred, D=64, H=8, e_layers=4, d_layers=3, F=64, cin=16, cout=16, stack=True,
+                  distil=True):
+    """GEMM-type work of one forward (multiply-adds x 2), counted as for the default configuration's
+    8.897 MFLOP: embeddings (3-tap conv), per attention layer Q/K/V/O + scores + context, FFN, the
+    distil conv on its L + 2 output rows, the projection of all decoder rows."""
+    HE, Ld = (D // H) * H, label + pred
+    f = 2 * (seq + Ld) * 3 * cin * D
+    cur, inp, mem = seq, seq, 0
+    for el in (range(e_layers, 2, -1) if stack else [e_layers]):
+        L = min(inp, cur)
+        for layer in range(el):
+            f += 8 * L * D * HE + 4 * L * L * HE + 4 * L * D * F
+            if distil and layer < el - 1:
+                f += 2 * (L + 2) * 3 * D * D
+                L = (L + 1) // 2 + 1
+        cur, mem, inp = L, mem + L, inp // 2
+    f += d_layers * (8 * Ld * D * HE + 4 * Ld * Ld * HE + 4 * Ld * D * HE + 4 * mem * D * HE + 4 * Ld * mem * HE
+                     + 4 * Ld * D * F)
+    return f + 2 * Ld * D * cout
 RNN_FLOP_PER_STEP = {"lstm": 1.614e6, "gru": 1.213e6, "rnn": 0.410e6}
 LMMSE_BYTES = {(16, 4): 688.0, (8, 4): 368.0, (4, 2): 120.0}
 PEAK_FP32_MFMA_TFLOPS = 157.3    # dense fp32 matrix peak of MI355X
@@ -475,6 +496,24 @@ def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
         "predictions_per_s": B / d2, "kernel_ms": d2 * 1e3,
         "mfma_frac": INFORMER_FLOP * B / d2 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "roofline": roof("mfma", INFORMER_FLOP * B / d2 / 1e12, d2 * 1e3)}
+    # the shipped 12-head / 35-slot / 25-decoder-row checkpoint (large one-wave launch shape)
+    h12 = np.load(os.path.join(GOLDEN, "informer_h12.npz"))
+    m12 = cet.InformerStack(16, 16, 16, 35, 20, 5, 5, 64, 12, 4, 3, 64, 0.05, "full", "fixed", "gelu",
+                            False, True)
+    m12.load_state_dict(torch_sd({k[len("h12/sd/"):].replace("module.", "", 1): h12[k]
+                                  for k in h12.files if k.startswith("h12/sd/")}))
+    m12 = m12.eval().to(dev)
+    noisy12, _ = synth.channel_histories_device(B, dev, T=40, seed=12)
+    x12 = cet.load_batch_device(noisy12[:, :35]).contiguous()
+    xd12 = cet.decoder_input(x12, 20, 5)
+    _w, d12 = timed_loop(lambda: m12(x12, xd12), max(5, args.steps // 5), 2, False, dev)
+    f12 = informer_flop(35, 20, 5, H=12)
+    extra["informer_12_heads_35_slots"] = {
+        "predictions_per_s": B / d12, "kernel_ms": d12 * 1e3, "flop_per_prediction": f12,
+        "roofline": roof("mfma", f12 * B / d12 / 1e12, d12 * 1e3),
+        "note": "shipped InformerStack_5x_d_model64_n_heads12_..._seq_len35_label_len20 checkpoint, "
+                f"B={B}, output_attention=False"}
+    del m12, x12, xd12, noisy12
     # the reference's own GPU path on this card: the model in stock PyTorch-ROCm eager
     # calls (oracle/torch_ref.py on device tensors), same weights, same batch
     from oracle import torch_ref as _tr
