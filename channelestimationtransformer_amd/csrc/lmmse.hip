@@ -716,7 +716,7 @@ __device__ inline void store_block_results(float* __restrict__ x_hat, float* __r
 // ring of two to four LDS buffers) was slower on every shape (16x4: 0.48 against 0.43 ms per
 // 8.4 M REs; it wrote 69 instead of 58 B/RE because the pieces of a 128-byte line arrive over two
 // stages), as was the streaming cache policy on the DMA: neither the vector unit (the packed
-// arithmetic removed a third of its instructions for 3 % of the time) nor the bytes in flight
+// arithmetic removed a seventh of its instructions for 3 % of the time) nor the bytes in flight
 // bound this kernel; with and without its stores it moves 4.0 to 4.3 TB/s.
 template <int NR, int NS, int LPR>
 __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
