@@ -14,6 +14,8 @@ container (weights read with weights_only=True, key names kept exactly as stored
                       first attention map
   rnn_more.npz        {GRU,LSTM,RNN}_CDLBFixedDirection_... and {GRU,LSTM,RNN}_best_model_params_
                       V30_uplink.pt: state_dict + 16 sequences -> rollouts at pred_len 5 and 25
+  rnn_pl3.npz         prediciton_code/checkpoints/checkpoints/{GRU,LSTM,RNN}_data_0_sl25_pl3_hs256_hl2
+                      (trained for pred_len 3): state_dict + 16 sequences -> rollouts at pred_len 3 and 5
   informer_h12.npz    InformerStack_5x_d_model64_n_heads12_..._seq_len35_label_len20_pred_len5_
                       ..._uplink.pt (12 heads of 5 features, 35-slot history): state_dict, 8 seeded
                       synthetic 40-slot histories -> every stage, every attention map, prediction
@@ -120,6 +122,22 @@ def main():
                     out[f"{name}_{tag}/pred{P}"] = m.test_data(x, P, "cpu").numpy()
             print(name, tag, len(ck), "keys", np.abs(out[f"{name}_{tag}/pred25"]).max())
     np.savez_compressed(os.path.join(HERE, "rnn_more.npz"), **out)
+
+    # ---- the recurrent checkpoints trained for pred_len 3 ---------------------------------------------
+    out = {"x": load_batch(data["60"][:16, :25]).numpy()}
+    x = torch.from_numpy(out["x"])
+    PL3 = "ExampleCodeTsinghua/prediciton_code/checkpoints/checkpoints/"
+    for name, cls in (("GRU", GRU), ("LSTM", LSTM), ("RNN", RNN)):
+        ck, plain = load_sd(PL3 + f"{name}_data_0_sl25_pl3_hs256_hl2/checkpoint.pth")
+        m = cls(16, 16, 256, 2)
+        m.load_state_dict(plain)
+        m.eval()
+        store_sd(out, name, ck)
+        with torch.no_grad():
+            for P in (3, 5):
+                out[f"{name}/pred{P}"] = m.test_data(x, P, "cpu").numpy()
+        print(name, "pl3", len(ck), "keys", np.abs(out[f"{name}/pred3"]).max())
+    np.savez_compressed(os.path.join(HERE, "rnn_pl3.npz"), **out)
 
     # ---- the 12-head, 35-slot checkpoint ------------------------------------------------------------------
     from channelestimationtransformer_amd import synth

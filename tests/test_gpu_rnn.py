@@ -176,6 +176,23 @@ def test_nmse_against_the_reference_on_its_stored_sequences(cell, kind, variant)
 
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("cell", ["GRU", "LSTM", "RNN"])
+def test_pred_len_3_checkpoints(cell, variant):
+    """prediciton_code/checkpoints/checkpoints/{GRU,LSTM,RNN}_data_0_sl25_pl3_hs256_hl2 against the
+    imported reference at pred_len 3 (what they were trained for) and 5."""
+    v = load_npz("rnn_pl3.npz")
+    m = getattr(cet, cell)(16, 16, 256, 2)
+    m.load_state_dict({k: torch.from_numpy(np.array(a)) for k, a in sub_dict(v, f"{cell}/sd").items()})
+    m.eval().select_kernel(variant)
+    x = torch.from_numpy(v["x"]).cuda()
+    for P in (3, 5):
+        want = v[f"{cell}/pred{P}"]
+        out = m.test_data(x, P, "cuda").cpu().numpy()
+        assert out.shape == want.shape
+        assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "RNN"])
 @pytest.mark.parametrize("tag", ["fixed_direction", "best"])
 def test_more_shipped_checkpoints(cell, tag, variant):
     """HPC/TrainedTransformers/{GRU,LSTM,RNN}_CDLBFixedDirection_..._uplink.pt and

@@ -170,6 +170,19 @@ def test_checker_on_more_shipped_recurrent_checkpoints(cell, kind, tag, oracle):
         assert np.abs(out - want).max() < 1e-5 * max(1.0, float(np.abs(want).max()))
 
 
+@pytest.mark.parametrize("cell,kind", [("GRU", 1), ("LSTM", 2), ("RNN", 0)])
+def test_checker_on_the_pred_len_3_recurrent_checkpoints(cell, kind, oracle):
+    """prediciton_code/checkpoints/checkpoints/{GRU,LSTM,RNN}_data_0_sl25_pl3_hs256_hl2: rollouts at
+    the pred_len they were trained for and at 5."""
+    v = load_npz("rnn_pl3.npz")
+    blob = blobs.pack_rnn(sub_dict(v, f"{cell}/sd"), kind, 16, 16, 256, 2)
+    for P in (3, 5):
+        want = v[f"{cell}/pred{P}"]
+        out = oracle.rnn_rollout(kind, 16, 16, 256, 2, blob, v["x"], P)
+        assert out.shape == want.shape
+        assert np.abs(out - want).max() < 1e-5 * max(1.0, float(np.abs(want).max()))
+
+
 def nmse_db_per_slot(pred, truth):
     return 10 * np.log10(((truth - pred) ** 2).sum((0, 2)) / (truth ** 2).sum((0, 2)))
 
