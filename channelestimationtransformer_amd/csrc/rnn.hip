@@ -456,6 +456,9 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
 // The grid (tiles x H / 16 workgroups, one per CU) must be resident at once: the launcher only
 // picks this kernel while the grid fits the device's CU count.
 constexpr int ST = 16;        // sequences per workgroup
+// Head of the scratch buffer (zeroed before every launch): arrival counters, one per tile and layer
+// (at most 32 tiles x 3 layers), and in the last word the grid's failure flag.
+constexpr size_t SPLIT_CNT_FLOATS = 128;  // 512 B
 constexpr int SPIN_LIMIT = 1 << 20;  // polls of about a microsecond each: a second or two
 
 DEV f32x4 mfma16(float a, float b, f32x4 c) {
@@ -580,6 +583,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
 
   float* const hx_tile = a.hx + (size_t)tile * NL * 2 * P * 256;
   unsigned* const cnt_tile = a.cnt + tile * NL;
+  unsigned* const fail = a.cnt + (SPLIT_CNT_FLOATS - 1);  // set by any workgroup whose wait ran out
 
   // Waits until every workgroup of the tile has published layer l of step t, then copies the
   // layer's full hidden state into hfull[l].
@@ -594,6 +598,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > SPIN_LIMIT) {
           dead = 1;
+          __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
       }
@@ -793,6 +798,17 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
     }
   }
   (void)bc;
+  // A wait that ran out anywhere in the grid (the workgroups were not all resident: the GPU was
+  // shared with other work) leaves garbage in the exchange. The predictions are then overwritten
+  // with NaN, so that such a rollout cannot pass for a result.
+  __syncthreads();
+  if (ug == 0 && (dead || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+    const int per_seq = a.pred_len * a.F;
+    for (int i = tid; i < ST * per_seq; i += 256) {
+      const int sq = i / per_seq;
+      if (b0 + sq < a.B) a.out[(size_t)(b0 + sq) * per_seq + (i - sq * per_seq)] = __builtin_nanf("");
+    }
+  }
 }
 
 // Scratch of the hidden-split kernel: arrival counters (one per tile and layer, in a block of
@@ -800,7 +816,6 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
 // [tile][layer][parity][unit group][256 floats].
 constexpr int SPLIT_MAX_WG = 256;    // workgroups the static buffer below serves (tiles x H / 16)
 constexpr int SPLIT_MAX_LAYERS = 3;
-constexpr size_t SPLIT_CNT_FLOATS = 128;  // 512 B: room for 128 counters >= 32 tiles x 3 layers
 constexpr size_t SPLIT_MAX_FLOATS = SPLIT_CNT_FLOATS + (size_t)SPLIT_MAX_WG * SPLIT_MAX_LAYERS * 2 * 256;
 
 // The buffer of the entry point that allocates nothing (cet_rnn_rollout_static): 1.5 MiB per GPU
@@ -1043,6 +1058,7 @@ static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, hipSt
 static int split_tiles(int B) { return (B + ST - 1) / ST; }
 static bool split_fits(const RnnModel* m, int B, int max_wg) {
   const long wg = (long)split_tiles(B) * (m->H / 16);
+  if ((size_t)split_tiles(B) * m->layers > SPLIT_CNT_FLOATS - 1) return false;  // counters + failure flag
   return wg <= m->cus && wg <= max_wg;
 }
 

@@ -153,7 +153,9 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
  * kernel for small batches (16 sequences and 16 hidden units per workgroup, hidden states
  * exchanged through a scratch buffer once per layer and step; needs ceil(B / 16) * hidden / 16
- * workgroups resident at once, i.e. at most the device's CU count, else CET_ERR_TOO_LARGE).
+ * workgroups resident at once, i.e. at most the device's CU count, else CET_ERR_TOO_LARGE; when
+ * other work on the GPU keeps part of that grid from becoming resident, the exchange gives up
+ * after about a second and the predictions of the call are NaN instead of a result).
  * Not to be called while a rollout of the same handle runs on another thread. No counterpart in
  * the reference. */
 int cet_rnn_select(cet_handle h, int kernel);
