@@ -457,8 +457,12 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
 // picks this kernel while the grid fits the device's CU count.
 constexpr int ST = 16;        // sequences per workgroup
 // Head of the scratch buffer (zeroed before every launch): arrival counters, one per tile and layer
-// (at most 32 tiles x 3 layers), and in the last word the grid's failure flag.
-constexpr size_t SPLIT_CNT_FLOATS = 128;  // 512 B
+// (at most 32 tiles x 3 layers), each in a 128-byte line of its own (with all of them in one
+// 512-byte block every poll and every arrival of the whole grid went to one memory channel), and in
+// the last word the grid's failure flag.
+constexpr int CNT_STRIDE = 32;                 // words between counters
+constexpr size_t SPLIT_CNT_SLOTS = 127;        // counters the header has room for
+constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 16 KiB
 constexpr int SPIN_LIMIT = 1 << 20;  // polls of about a microsecond each: a second or two
 
 DEV f32x4 mfma16(float a, float b, f32x4 c) {
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
   __syncthreads();
 
   float* const hx_tile = a.hx + (size_t)tile * NL * 2 * P * 256;
-  unsigned* const cnt_tile = a.cnt + tile * NL;
+  unsigned* const cnt_tile = a.cnt + (size_t)tile * NL * CNT_STRIDE;
   unsigned* const fail = a.cnt + (SPLIT_CNT_FLOATS - 1);  // set by any workgroup whose wait ran out
 
   // Waits until every workgroup of the tile has published layer l of step t, then copies the
@@ -593,8 +597,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
     if (tid == 0 && !dead) {
       const unsigned target = (unsigned)P * (unsigned)(t + 1), target2 = (unsigned)P * (unsigned)(t2 + 1);
       int spins = 0;
-      while (__hip_atomic_load(cnt_tile + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target ||
-             (l2 >= 0 && __hip_atomic_load(cnt_tile + l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target2)) {
+      while (__hip_atomic_load(cnt_tile + l * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target ||
+             (l2 >= 0 &&
+              __hip_atomic_load(cnt_tile + l2 * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target2)) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > SPIN_LIMIT) {
           dead = 1;
@@ -750,7 +755,8 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
         for (int i = 0; i < 4; ++i)  // element i * 64 + lane: 256 contiguous bytes per store instruction
           __hip_atomic_store(dst + i * 64 + lane, hn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(cnt_tile + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0)
+          __hip_atomic_fetch_add(cnt_tile + l * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (l < NL - 1) {
         if (l == NL - 2 && pending_top) {  // the layer above needs both: one wait, one round trip
@@ -1058,7 +1064,7 @@ static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, hipSt
 static int split_tiles(int B) { return (B + ST - 1) / ST; }
 static bool split_fits(const RnnModel* m, int B, int max_wg) {
   const long wg = (long)split_tiles(B) * (m->H / 16);
-  if ((size_t)split_tiles(B) * m->layers > SPLIT_CNT_FLOATS - 1) return false;  // counters + failure flag
+  if ((size_t)split_tiles(B) * m->layers > SPLIT_CNT_SLOTS) return false;  // counters + failure flag
   return wg <= m->cus && wg <= max_wg;
 }
 
