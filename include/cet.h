@@ -152,8 +152,10 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
 /* Pins the kernel of later rollouts of this handle (tests and timing): 0 by batch size, 1 the
  * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
  * kernel for small batches (16 sequences and 16 hidden units per workgroup, hidden states
- * exchanged through a scratch buffer once per layer and step; needs ceil(B / 16) * hidden / 16
- * workgroups resident at once, i.e. at most the device's CU count, else CET_ERR_TOO_LARGE; when
+ * exchanged through a scratch buffer once per layer and step; one launch takes as many sequences
+ * as ceil(B / 16) * hidden / 16 workgroups fit the device's CU count, all resident at once, and
+ * larger batches go through it in chunks, launch after launch - which choice 0 does for as long
+ * as it beats the batch-tiled kernel, a few chunks; when
  * other work on the GPU keeps part of that grid from becoming resident, the exchange gives up
  * after about a second and the predictions of the call are NaN instead of a result).
  * Not to be called while a rollout of the same handle runs on another thread. No counterpart in
