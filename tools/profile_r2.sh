@@ -23,7 +23,7 @@ WL[rnn]="--workload rnn --pred-len 5"
 WL[lmmse]="--workload lmmse --batch 8388608"
 WL[lmmse_block]="--workload lmmse --batch 8388608 --h-share 14"
 for w in informer informer_nomaps lstm gru rnn lmmse lmmse_block; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $REPO/bench.py --steps 20 --warmup 3 --skip-cpu-baseline --skip-secondary ${WL[$w]} > $OUT/trace_$w.log 2>&1 || { tail -5 $OUT/trace_$w.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $REPO/bench.py --steps 200 --warmup 50 --skip-cpu-baseline --skip-secondary ${WL[$w]} > $OUT/trace_$w.log 2>&1 || { tail -5 $OUT/trace_$w.log; exit 1; }
   for p in A B C; do
     eval "CNT=\$PASS_$p"
     timeout -s KILL 150 rocprofv3 --pmc $CNT --output-format csv -d $OUT/pmc_${w}_$p -- python3 $REPO/bench.py --steps 3 --warmup 1 --skip-cpu-baseline --skip-secondary ${WL[$w]} > $OUT/pmc_${w}_$p.log 2>&1 || { tail -5 $OUT/pmc_${w}_$p.log; exit 1; }
