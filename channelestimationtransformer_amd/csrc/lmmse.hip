@@ -360,6 +360,18 @@ __device__ inline void dma16(const void* src, unsigned lds_addr_wave_uniform) {
       : "v"(src), "s"(lds_addr_wave_uniform)
       : "memory");
 }
+// The same with the source as a wave-uniform base (scalar registers) plus a 32-bit offset per lane:
+// no 64-bit vector arithmetic per instruction.
+__device__ inline void dma16_base(const void* base_wave_uniform, unsigned lane_offset,
+                                  unsigned lds_addr_wave_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_offset), "s"(base_wave_uniform), "s"(lds_addr_wave_uniform)
+      : "memory");
+}
 __device__ inline void dma4(const void* src, unsigned lds_addr_wave_uniform) {
   unsigned keep;
   asm volatile(
@@ -632,7 +644,7 @@ __global__ __launch_bounds__(64, CET_TILED_WPS(NR, NS, LPR)) void lmmse_tiled(co
   }
 }
 
-// s_waitcnt vmcnt(n) for a run-time n (the count is an immediate; n above 16 waits for 16).
+// s_waitcnt vmcnt(n) for a run-time n (the count is an immediate; n above 32 waits for 32).
 template <int LO, int HI>
 __device__ inline void wait_vmcnt_range(int n) {
   if constexpr (LO == HI) {
@@ -643,7 +655,7 @@ __device__ inline void wait_vmcnt_range(int n) {
     else wait_vmcnt_range<MID + 1, HI>(n);
   }
 }
-__device__ inline void wait_vmcnt_upto16(int n) { wait_vmcnt_range<0, 16>(n < 16 ? n : 16); }
+__device__ inline void wait_vmcnt_upto32(int n) { wait_vmcnt_range<0, 32>(n < 32 ? n : 32); }
 
 // Result stores of the block-fading kernels: x_hat (or the LLRs) and no_eff of resource element
 // `re`. With two lanes per block and four streams each lane stores two streams (p = which);
@@ -689,6 +701,31 @@ __device__ inline void store_block_results(float* __restrict__ x_hat, float* __r
   }
 }
 
+// x_hat (or the LLRs) of element `e` of a tile into the tile's LDS staging area, which has the
+// layout of the output itself.
+template <int NS, int LPR>
+__device__ inline void stage_block_results(char* xs, int e, int p, const pair2 (&x)[NS]) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  float* xd = reinterpret_cast<float*>(xs) + (size_t)e * NS * 2;
+  if constexpr (LPR == 2 && NS == 4) {
+    const pair2 xa = p ? x[2] : x[0], xb = p ? x[3] : x[1];
+    *reinterpret_cast<v4f*>(xd + 4 * p) = v4f{xa.x, xa.y, xb.x, xb.y};
+  } else {
+    if (p != 0) return;
+    if constexpr (NS % 2 == 0) {
+#pragma unroll
+      for (int s = 0; s < NS; s += 2) {
+        const pair2 xa = x[s], xb = x[s + 1];
+        *reinterpret_cast<v4f*>(xd + 2 * s) = v4f{xa.x, xa.y, xb.x, xb.y};
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<v2f*>(xd + 2 * s) = x[s];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Block fading with a shared factorisation (scalar noise): one channel matrix per `hs`
 // consecutive REs. A wave owns a tile of T blocks. Its work is a sequence of equally sized
@@ -713,17 +750,17 @@ __device__ inline void store_block_results(float* __restrict__ x_hat, float* __r
 // One wave per SIMD for the large shapes: the matrices, a stage of received vectors and the
 // factor live in registers (about 300 of the 512 a lone wave may use). A variant for two waves
 // per SIMD (only the matrices and the factor in registers, the received vectors consumed from a
-// ring of two to four LDS buffers) was slower on every shape (16x4: 0.48 against 0.43 ms per
-// 8.4 M REs; it wrote 69 instead of 58 B/RE because the pieces of a 128-byte line arrive over two
-// stages), as was the streaming cache policy on the DMA: neither the vector unit (the packed
-// arithmetic removed a seventh of its instructions for 3 % of the time) nor the bytes in flight
-// bound this kernel; with and without its stores it moves 4.0 to 4.3 TB/s.
+// ring of two to four LDS buffers) was slower on every shape, as was the streaming cache policy
+// on the DMA: neither the vector unit (the packed arithmetic removed a seventh of its
+// instructions for 3 % of the time) nor the bytes in flight bound this kernel. What did was the
+// shape of its stores (see `stage_out` below); with whole-line stores 16x4 moves 5.0 TB/s, which
+// is what a bare DMA stream with any share of stores reaches on this memory system.
 template <int NR, int NS, int LPR>
 __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
                                                   const float* __restrict__ H, float lam,
                                                   float* __restrict__ x_hat,
                                                   float* __restrict__ no_eff, long N, int hs,
-                                                  long n_blocks, long n_tiles) {
+                                                  long n_blocks, long n_tiles, int stage_out) {
   constexpr int T = 64 / LPR;             // blocks per tile
   constexpr int HB = NR * NS * 8;         // bytes of H per block
   constexpr int YB = NR * 8;              // bytes of y per RE
@@ -736,6 +773,15 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
 
   __shared__ __attribute__((aligned(16))) char smem[CET_BLOCK_GM * H_TILE];
+  // stage_out: the results of a tile (T blocks x hs symbols: one contiguous range of x_hat and one
+  // of no_eff) leave as whole 1 KiB store instructions when the tile is done. x_hat is collected
+  // here (T * hs * NS * 8 bytes), followed by the no_eff of each block (T * NS * 4 bytes; the same
+  // for all symbols of a block). Stored symbol by symbol a wave's store instruction touches 64
+  // lines with 16 or 32 bytes each, a block's line is completed over two stages and a quarter of
+  // the lines left the L2 before that (58.5 B/RE written for 48): 0.416 against 0.358 ms per
+  // 8.4 M REs of 16x4, and twice the time on the small shapes.
+  extern __shared__ __attribute__((aligned(16))) char out_stage[];
+  char* const ne_stage = out_stage + (size_t)T * hs * NS * 8;
 
   const int lane = threadIdx.x;
   const int t = lane & (T - 1);  // block within the tile
@@ -750,11 +796,35 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   };
 
   // stage st of a tile: 0 = the matrices, g + 1 = symbols g*GS .. of every block
+  // Offsets of this lane's 16-byte pieces inside a tile, for the DMA instructions of a stage: the
+  // source of a complete tile is a wave-uniform base (scalar arithmetic) plus these, so that an
+  // instruction costs no vector address arithmetic (it was 16 to 20 vector instructions each, a
+  // third of the kernel's vector work). Tiles at the ragged end take the general path.
+  unsigned yoff[YS_INSTR];
+#pragma unroll
+  for (int i = 0; i < YS_INSTR; ++i) {
+    const int P = i * 64 + lane;
+    const int tt = P / CY, q = P % CY;
+    yoff[i] = (unsigned)tt * (unsigned)hs * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4);
+  }
+  const bool small_tiles = (long)T * hs * YB < (1l << 31);  // the offsets fit 32 bits
+
   auto issue = [&](long tile, int st) {
     const unsigned dst = lds_address(smem);
     const long blk0 = tile * T;
     const int kmax = symbols_of(tile);
+    const bool whole = small_tiles && (blk0 + T) * hs <= N;  // every block and symbol of the tile exists
     if (st == 0) {
+      if (whole) {
+        const char* base = reinterpret_cast<const char*>(H) + blk0 * HB;
+#pragma unroll
+        for (int i = 0; i < H_INSTR; ++i) {
+          const int P = i * 64 + lane;
+          const int tt = P / CH, q = P % CH;
+          dma16_base(base, (unsigned)(tt * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4)), dst + i * 1024);
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < H_INSTR; ++i) {
         const int P = i * 64 + lane;
@@ -769,6 +839,12 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
 #pragma unroll
       for (int j = 0; j < GS; ++j) {
         if (k0 + j < kmax) {
+          if (whole) {
+            const char* base = reinterpret_cast<const char*>(y) + (blk0 * hs + k0 + j) * YB;
+#pragma unroll
+            for (int i = 0; i < YS_INSTR; ++i) dma16_base(base, yoff[i], dst + (j * YS_INSTR + i) * 1024);
+            continue;
+          }
 #pragma unroll
           for (int i = 0; i < YS_INSTR; ++i) {
             const int P = i * 64 + lane;
@@ -860,6 +936,10 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
       }
     }
     lmmse_factor<NS>(g, lam, f);
+    if (stage_out && !llr_mode && p == 0) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) reinterpret_cast<float*>(ne_stage)[t * NS + s] = f.ne[s];
+    }
   };
 
   // The matched filter takes every matrix entry as a broadcast pair (re, re) / (im, im), which a
@@ -908,9 +988,43 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
       if (llr_mode) to_llr<NS>(x, ne);
       const long blk = tile * T + t;
       const long re = blk * hs + k0 + j;
-      if (blk < n_blocks && re < N && (!(CET_BLOCK_ABLATE & 1) || lam < -1.0f))
+      if (stage_out) {
+        stage_block_results<NS, LPR>(out_stage, t * hs + k0 + j, p, x);
+      } else if (blk < n_blocks && re < N && (!(CET_BLOCK_ABLATE & 1) || lam < -1.0f)) {
         store_block_results<NS, LPR>(x_hat, no_eff, re, p, x, ne);
+      }
     }
+  };
+  // The tile's staged results to global memory: 16 bytes per lane and instruction, contiguous.
+  // Returns the number of store instructions issued.
+  const float inv_hs = 1.0f / (float)hs;
+  auto flush_tile = [&](long tile) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const long re0 = tile * T * hs;
+    const long n_re = N - re0 < (long)T * hs ? N - re0 : (long)T * hs;  // elements of this tile
+    const int xb = (int)n_re * NS * 8, nb = llr_mode ? 0 : (int)n_re * NS * 4;
+    char* xg = reinterpret_cast<char*>(x_hat) + re0 * NS * 8;
+    for (int o = lane * 16; o < xb; o += 1024)
+      *reinterpret_cast<v4f*>(xg + o) = *reinterpret_cast<const v4f*>(out_stage + o);
+    if (nb) {
+      char* ng = reinterpret_cast<char*>(no_eff) + re0 * NS * 4;
+      const float* nsrc = reinterpret_cast<const float*>(ne_stage);
+      constexpr int RP = 4 / NS;  // elements per 16-byte piece (NS is 1, 2 or 4)
+      for (int o = lane * 16; o < nb; o += 1024) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+          // block of element e: e / hs (e < 2^16: the rounded product is off by < 1e-3, the
+          // quotient of e + 0.5 at least 0.5 / hs from an integer)
+          const int e = o / (NS * 4) + r;
+          const int blk = (int)(((float)e + 0.5f) * inv_hs);
+#pragma unroll
+          for (int s2 = 0; s2 < NS; ++s2) v[r * NS + s2] = nsrc[blk * NS + s2];
+        }
+        *reinterpret_cast<v4f*>(ng + o) = v4f{v[0], v[1], v[2], v[3]};
+      }
+    }
+    return (xb + 1023) / 1024 + (nb + 1023) / 1024;
   };
 
   // Stage pipeline. vmcnt retires vector-memory instructions in issue order; the instructions
@@ -925,7 +1039,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   if (tile < n_tiles) issue(tile, 0);
   while (tile < n_tiles) {
     if (CET_BLOCK_ABLATE & 1) younger = 0;
-    wait_vmcnt_upto16(younger);
+    wait_vmcnt_upto32(younger);
     const int kmax = symbols_of(tile);
     const int n_here = 1 + (kmax + GS - 1) / GS;  // stages of this tile
     const int k0 = (st - 1) * GS;
@@ -946,12 +1060,24 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
     } else {
       equalise(tile, k0, nsym);
       const bool full_tile = (tile * T + T) * hs <= N;
-      younger = full_tile ? nsym * (ST_X + (llr_mode ? 0 : 1)) : 1;
+      if (stage_out) {
+        younger = 0;
+        if (st == n_here - 1) {  // the tile is complete
+          const int issued = flush_tile(tile);
+          younger = full_tile ? issued : 1;
+        }
+      } else {
+        younger = full_tile ? nsym * (ST_X + (llr_mode ? 0 : 1)) : 1;
+      }
     }
     tile = ntile;
     st = nst;
   }
 }
+
+// Output staging of the block-fading kernel is used while the stage buffer and a tile's results
+// fit this many bytes of LDS together (16x4, 14 symbols per block: 16 + 14.5 KiB; 8x4: 16 + 29).
+constexpr int BLOCK_LDS_MAX = 64 * 1024;
 
 template <int NR, int NS, int LPR>
 int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, float* no_eff,
@@ -963,19 +1089,29 @@ int launch_block(const float* y, const float* H, float no_scalar, float* x_hat, 
   CET_HIP(hipGetDevice(&dev));
   CET_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const auto kernel = &lmmse_block<NR, NS, LPR>;
-  // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per CU
-  static std::atomic<int> per_cu_cached{0};  // a property of the kernel's registers and LDS
-  int per_cu = per_cu_cached.load(std::memory_order_relaxed);
+  // Results staged through LDS when a tile's fit: faster on every shape, also where the staging
+  // area lowers the number of resident waves (8x4: two per CU instead of four).
+  const long out_bytes = (long)T * NS * (hshare * 8l + 4);
+  bool stage = out_bytes <= BLOCK_LDS_MAX - T * NR * NS * 8;
+#ifdef CET_EXP  // experiment build only: CET_BLOCK_STAGE=0 switches the staging off
+  if (const char* e = getenv("CET_BLOCK_STAGE")) stage = stage && e[0] == '1';
+#endif
+  const size_t dyn = stage ? (size_t)((out_bytes + 1023) / 1024 * 1024) : 0;
+  // persistent waves: as many as are resident at once (registers and LDS decide), at most 8 per
+  // CU; the answer for the last staging size is kept (a property of the kernel otherwise)
+  static std::atomic<long> cached{-1};  // dyn * 16 + waves per CU
+  const long c = cached.load(std::memory_order_relaxed);
+  int per_cu = c >= 0 && (size_t)(c >> 4) == dyn ? (int)(c & 15) : 0;
   if (!per_cu) {
     int nb = 0;
-    CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 64, 0));
+    CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 64, dyn));
     per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
-    per_cu_cached.store(per_cu, std::memory_order_relaxed);
+    cached.store((long)dyn * 16 + per_cu, std::memory_order_relaxed);
   }
   long grid = (long)cus * per_cu;
   if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64), 0, stream, y, H, no_scalar, x_hat,
-                     no_eff, N, hshare, n_blocks, n_tiles);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64), dyn, stream, y, H, no_scalar, x_hat,
+                     no_eff, N, hshare, n_blocks, n_tiles, stage ? 1 : 0);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }

@@ -207,6 +207,26 @@ def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, kernel, oracle
         cet.lmmse(yt, Hbt[:-1] if nb > 1 else Ht[:0], 0.1, h_share=h_share)
 
 
+@pytest.mark.parametrize("Nr,Ns", [(16, 4), (16, 2), (16, 1), (8, 4), (8, 2), (4, 4), (4, 2), (2, 2), (2, 1)])
+def test_block_fading_staged_results_every_shape(Nr, Ns):
+    """The shared-factorisation kernel collects a tile's results in LDS and stores them as whole
+    lines when they fit (and stores them directly when they do not): block lengths on both sides
+    of that limit, odd ones (a 16-byte piece of no_eff then spans two blocks when Ns < 4), a
+    ragged last block and tile, and enough tiles that every wave works on several in a row — bit
+    for bit what the per-element kernel returns on the expanded channel, demapper included."""
+    for h_share, nb in ((14, 150000), (7, 9001), (13, 5000), (28, 3000), (97, 700)):
+        N = h_share * nb - (h_share // 2)
+        g = torch.Generator(device="cuda").manual_seed(Nr * 100 + Ns + h_share)
+        yt = torch.view_as_complex(torch.randn(N, Nr, 2, device="cuda", generator=g))
+        Hbt = torch.view_as_complex(torch.randn(nb, Nr, Ns, 2, device="cuda", generator=g))
+        Ht = Hbt.repeat_interleave(h_share, dim=0)[:N]
+        x0, ne0 = cet.lmmse(yt, Ht, 0.07)
+        x1, ne1 = cet.lmmse(yt, Hbt, 0.07, h_share=h_share)
+        assert torch.equal(torch.view_as_real(x0), torch.view_as_real(x1)) and torch.equal(ne0, ne1)
+        assert torch.equal(cet.lmmse_llr(yt, Ht, 0.07), cet.lmmse_llr(yt, Hbt, 0.07, h_share=h_share))
+        del Ht, x0, x1, ne0, ne1
+
+
 @pytest.mark.parametrize("ant,ntx,nst", [(4, 1, 2), (16, 2, 2), (8, 1, 1), (2, 1, 2)])
 def test_equalizer_object_reads_the_grid_in_place(ant, ntx, nst, oracle):
     """The equalizer object hands y [b,1,ant,sym,fft] and h_hat [b,1,ant,tx,st,sym,sc] to one

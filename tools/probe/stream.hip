@@ -103,10 +103,13 @@ int main() {
   timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, strided, swizzled src", [&] { dma<16, true, false><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
   timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, contiguous per wave", [&] { dma<16, false, true><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
   f32x4* wd;
-  hipMalloc(&wd, bytes / 8);
+  hipMalloc(&wd, bytes / 2);
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 1 KiB store per tile (6%)", [&] { dma<16, false, false, 1><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 1 KiB nt store per tile", [&] { dma<16, false, false, 10><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 2 KiB store per tile (12%)", [&] { dma<16, false, false, 2><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (18.0 / 16));
+  timeit("LDS-DMA 16 KiB x2, 1024 waves + 4 KiB store per tile (25%)", [&] { dma<16, false, false, 4><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (20.0 / 16));
+  timeit("LDS-DMA 16 KiB x2, 1024 waves + 6 KiB store per tile (37%)", [&] { dma<16, false, false, 6><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (22.0 / 16));
+  timeit("LDS-DMA 16 KiB x2, 1024 waves + 8 KiB store per tile (50%)", [&] { dma<16, false, false, 8><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (24.0 / 16));
   timeit("LDS-DMA 16 KiB tiles x2, 2048 waves (grid), strided", [&] { dma<16, false, false><<<2048, 64>>>(src, out, bytes / 16384); }, bytes);
   timeit("LDS-DMA 8 KiB tiles x2, 2048 waves resident, strided", [&] { dma<8, false, false><<<2048, 64>>>(src, out, bytes / 8192); }, bytes);
   timeit("LDS-DMA 8 KiB tiles x2, 2048 waves resident, swizzled", [&] { dma<8, true, false><<<2048, 64>>>(src, out, bytes / 8192); }, bytes);
