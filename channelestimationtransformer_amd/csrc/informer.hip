@@ -724,18 +724,19 @@ DEV void activate(Act& h, int activation) {
     for (int m = 0; m < 4; ++m) h[rt][m] = act(h[rt][m], activation);
 }
 
-// LDS regions of a wave: one-wave kernel Q | K | V (R rows each), workgroup kernel K | V (the
-// queries stay in registers). A padded tile read may run into the next region (finite data).
-template <bool WG, int NHP>
+// LDS regions of a wave: Q | K | V (R rows each), or K | V where the queries stay in registers
+// (QR: the workgroup kernel and the large one-wave shapes). A padded tile read may run into the
+// next region (finite data).
+template <bool QR, int NHP>
 DEV float* region_q(float* smem, int R) { return smem; }
-template <bool WG, int NHP>
-DEV float* region_k(float* smem, int R) { return WG ? smem : smem + R * ldq<NHP>(); }
-template <bool WG, int NHP>
-DEV float* region_v(float* smem, int R) { return WG ? smem + R * ldq<NHP>() : smem + 2 * R * ldq<NHP>(); }
+template <bool QR, int NHP>
+DEV float* region_k(float* smem, int R) { return QR ? smem : smem + R * ldq<NHP>(); }
+template <bool QR, int NHP>
+DEV float* region_v(float* smem, int R) { return QR ? smem + R * ldq<NHP>() : smem + 2 * R * ldq<NHP>(); }
 
-// The three projections of an attention layer: K and V go to LDS, Q to LDS (one-wave kernel)
-// or stays in registers (workgroup kernel).
-template <int RQ, int RK, bool WG, int NHP>
+// The three projections of an attention layer: K and V go to LDS, Q to LDS or (QR) stays in
+// registers.
+template <int RQ, int RK, bool WG, bool QR, int NHP>
 DEV void project_qkv(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
                      const Act& xq, const Act& xkv, int Lq, int Lk,
                      Act& q) {
@@ -745,13 +746,13 @@ DEV void project_qkv(const float* __restrict__ w, Stage& st, float* smem, int R,
   wave_sync();  // earlier reads of the regions are issued
   next_weights<WG, NHP, 4>(A, st, w, ln);
   wmul<RQ, NHP, 4>(A, xq, q);
-  if (!WG) store_rows<RQ, NHP, LDQ>(region_q<WG, NHP>(smem, R), ln, q, Lq);
+  if (!QR) store_rows<RQ, NHP, LDQ>(region_q<QR, NHP>(smem, R), ln, q, Lq);
   next_weights<WG, NHP, 4>(A, st, w + sz_qkv<NHP>(), ln);
   wmul<RK, NHP, 4>(A, xkv, t);
-  store_rows<RK, NHP, LDQ>(region_k<WG, NHP>(smem, R), ln, t, Lk);
+  store_rows<RK, NHP, LDQ>(region_k<QR, NHP>(smem, R), ln, t, Lk);
   next_weights<WG, NHP, 4>(A, st, w + 2 * sz_qkv<NHP>(), ln);
   wmul<RK, NHP, 4>(A, xkv, t);
-  store_rows<RK, NHP, LDQ>(region_v<WG, NHP>(smem, R), ln, t, Lk);
+  store_rows<RK, NHP, LDQ>(region_v<QR, NHP>(smem, R), ln, t, Lk);
   wave_sync();
   PROF_MARK(ln, P_QKV);
 }
@@ -759,7 +760,7 @@ DEV void project_qkv(const float* __restrict__ w, Stage& st, float* smem, int R,
 // EncoderLayer.forward (encoder.py:37-53) with AttentionLayer / FullAttention (attn.py).
 // Block: q,k,v,o Linear | conv1 | conv2 | norm1 g,b | norm2 g,b.
 template <int NHP> constexpr int sz_enc_layer() { return sz_attn<NHP>() + SZ_FFN + 4 * DM; }
-template <int RT, bool WG, int NHP>
+template <int RT, bool WG, bool QR, int NHP>
 DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
                        int L, int activation, float* amap, Act& x, int pack_L = 0,
                        float* amap2 = nullptr) {
@@ -768,9 +769,9 @@ DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
   WFrag A;
   NormParams n;
   Act t, y;
-  project_qkv<RT, RT, WG, NHP>(w, st, smem, R, ln, x, x, L, L, t);
-  attention<RT, RT, WG, NHP>(t, region_q<WG, NHP>(smem, R), region_k<WG, NHP>(smem, R),
-                             region_v<WG, NHP>(smem, R), L, L, false, ln, y, amap, pack_L, amap2);
+  project_qkv<RT, RT, WG, QR, NHP>(w, st, smem, R, ln, x, x, L, L, t);
+  attention<RT, RT, QR, NHP>(t, region_q<QR, NHP>(smem, R), region_k<QR, NHP>(smem, R),
+                             region_v<QR, NHP>(smem, R), L, L, false, ln, y, amap, pack_L, amap2);
   PROF_MARK(ln, P_ATTN);
   next_weights<WG, 4, NHP>(A, st, w + 3 * sz_qkv<NHP>(), ln, &n, nw);  // output projection, norm1
   wmul<RT, 4, NHP>(A, y, t);
@@ -792,13 +793,13 @@ DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
 // DecoderLayer.forward (decoder.py:20-36).
 // Block: self q,k,v,o | cross q,k,v,o | conv1 | conv2 | norm1 | norm2 | norm3.
 template <int NHP> constexpr int sz_dec_layer() { return 2 * sz_attn<NHP>() + SZ_FFN + 6 * DM; }
-template <int RD, int RM, bool WG, int NHP>
+template <int RD, int RM, bool WG, bool QR, int NHP>
 DEV void decoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
                        int Ld, int Lm, int activation, const Act& mem, Act& x) {
   constexpr int SZ_ATTN = sz_attn<NHP>();
-  float* Qb = region_q<WG, NHP>(smem, R);
-  float* Kb = region_k<WG, NHP>(smem, R);
-  float* Vb = region_v<WG, NHP>(smem, R);
+  float* Qb = region_q<QR, NHP>(smem, R);
+  float* Kb = region_k<QR, NHP>(smem, R);
+  float* Vb = region_v<QR, NHP>(smem, R);
   const float* wc = w + SZ_ATTN;       // cross attention
   const float* wf = w + 2 * SZ_ATTN;   // conv1 | conv2
   const float* nw = wf + SZ_FFN;
@@ -806,8 +807,8 @@ DEV void decoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
   NormParams n;
   Act t, y;
   // causal self attention
-  project_qkv<RD, RD, WG, NHP>(w, st, smem, R, ln, x, x, Ld, Ld, t);
-  attention<RD, RD, WG, NHP>(t, Qb, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
+  project_qkv<RD, RD, WG, QR, NHP>(w, st, smem, R, ln, x, x, Ld, Ld, t);
+  attention<RD, RD, QR, NHP>(t, Qb, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
   next_weights<WG, 4, NHP>(A, st, w + 3 * sz_qkv<NHP>(), ln, &n, nw);  // output projection, norm1
   wmul<RD, 4, NHP>(A, y, t);
@@ -816,8 +817,8 @@ DEV void decoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
   layer_norm<RD>(x, n, ln);
   PROF_MARK(ln, P_ADDLN);
   // cross attention: queries from x, keys / values from the encoder memory
-  project_qkv<RD, RM, WG, NHP>(wc, st, smem, R, ln, x, mem, Ld, Lm, t);
-  attention<RD, RM, WG, NHP>(t, Qb, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
+  project_qkv<RD, RM, WG, QR, NHP>(wc, st, smem, R, ln, x, mem, Ld, Lm, t);
+  attention<RD, RM, QR, NHP>(t, Qb, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
   next_weights<WG, 4, NHP>(A, st, wc + 3 * sz_qkv<NHP>(), ln, &n, nw + 2 * DM);  // output projection, norm2
   wmul<RD, 4, NHP>(A, y, t);
@@ -1148,7 +1149,7 @@ struct Cursor {
 };
 
 // One encoder step on RT row tiles (RM: tiles of the memory).
-template <int RT, int RM, bool WG, int NHP>
+template <int RT, int RM, bool WG, bool QR, int NHP>
 DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem, int R, const Lane ln,
                 int b, Act& x, Act& mem) {
   const int L = op.L;
@@ -1158,7 +1159,7 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
       amap = cu.attn + (size_t)b * a.n_heads * L * L;
       cu.attn += (size_t)a.B * a.n_heads * L * L;
     }
-    encoder_layer<RT, WG, NHP>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
+    encoder_layer<RT, WG, QR, NHP>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
     if (!ABLATED(a, 8)) cu.w += sz_enc_layer<NHP>();
     tap<RT>(cu.taps, a.B, b, L, ln, x);
   } else if (op.type == OP_DISTIL) {
@@ -1192,7 +1193,7 @@ DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float
       if (b2 >= 0) amap2 = cu.attn + (size_t)b2 * a.n_heads * L * L;
       cu.attn += (size_t)a.B * a.n_heads * L * L;
     }
-    encoder_layer<1, true, 4>(cu.w, st, smem, R, ln, 16, a.activation, amap, x, L, amap2);
+    encoder_layer<1, true, true, 4>(cu.w, st, smem, R, ln, 16, a.activation, amap, x, L, amap2);
     cu.w += sz_enc_layer<4>();
     tap_packed(cu.taps, a.B, b, b2, L, ln, x);
   } else if (op.type == OP_DISTIL) {
@@ -1251,10 +1252,14 @@ DEV void run_op_partner(const Op op, const KArgs& a, Cursor& cu, Stage& st, floa
 // RE: row tiles of the longest encoder step (2: sequences of up to 30 slots; 3: up to 46).
 // NHP: head pairs (4: up to 8 heads, 6: up to 12). The instantiations with three row tiles or
 // six head pairs ("large": the one-wave shape only) get the register budget of one wave per SIMD.
+template <int RE, int RD, int NHP>
+constexpr bool large_shape() { return RE > 2 || RD > 2 || NHP > 4; }
 template <int RE, int RD, int RM, bool WG, int NHP>
 __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
-                             (WG || RE > 2 || RD > 2 || NHP > 4) ? 1 : CET_WPS) void informer_kernel(const KArgs a) {
+                             (WG || large_shape<RE, RD, NHP>()) ? 1 : CET_WPS) void informer_kernel(const KArgs a) {
   static_assert(!WG || (RE <= 2 && RD <= 2 && NHP == 4), "the workgroup shape serves the 64-wide, 8-head family");
+  // queries in registers (and Q / K projections with permuted rows, see attention<.., QREG>)
+  constexpr bool QR = WG || large_shape<RE, RD, NHP>();
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   const int lane = threadIdx.x & 63;
   const int wave = WG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -1321,10 +1326,10 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
   // ---- encoder stack (encoder.py:87-101) ---------------------------------------------
   int i = 0;
   if (RE > 2)
-    for (; i < a.n_ops3; ++i) run_op<RE, RM, WG, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
-  for (; i < a.n_ops2; ++i) run_op<2, RM, WG, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+    for (; i < a.n_ops3; ++i) run_op<RE, RM, WG, QR, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  for (; i < a.n_ops2; ++i) run_op<2, RM, WG, QR, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
   const int n_plain = WG ? a.n_pack0 : a.n_ops;
-  for (; i < n_plain; ++i) run_op<1, RM, WG, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  for (; i < n_plain; ++i) run_op<1, RM, WG, QR, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
   if (WG && i < a.n_ops) {
     // hand the partner's rows to the primary (see "two sequences in one tile")
     const int L0 = a.ops[i].L;
@@ -1363,7 +1368,7 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
     PROF_MARK(ln, P_EMBED);
   }
   for (int l = 0; l < a.d_layers; ++l) {
-    decoder_layer<RD, RM, WG, NHP>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
+    decoder_layer<RD, RM, WG, QR, NHP>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
     if (!ABLATED(a, 8)) cu.w += sz_dec_layer<NHP>();
     tap<RD>(cu.taps, a.B, b, Ld, ln, x);
   }
@@ -1419,10 +1424,51 @@ struct InformerModel {
   // cet_informer_select; never read from the environment in the launch path.
   int kernel_choice = 0;
   bool pack = true;
+  bool large = false;  // large_model(): its query / key projections are stored row-permuted
 };
 
 // Head pairs the kernels run a model with: 4 (up to 8 heads) or 6 (up to 12).
 static int head_pairs(const cet_informer_cfg& c) { return c.n_heads <= 8 ? 4 : 6; }
+
+// Steps of the encoder stack (encoder.py:87-101) into a.ops / n_ops / n_ops2 / n_ops3 / mem_rows.
+static void encoder_steps(const Dims& d, KArgs& a) {
+  int n = 0, cur = d.seq_len, inp_len = d.seq_len, mem_rows = 0, n2 = 0, n3 = 0;
+  auto push = [&](int type, int L, int p, int q, int need) {
+    a.ops[n] = Op{(unsigned char)type, (unsigned char)L, (unsigned char)p, (unsigned char)q};
+    if (need > 16) n2 = n + 1;
+    if (need > 32) n3 = n + 1;
+    ++n;
+  };
+  for (int e = 0; e < d.n_enc; ++e) {
+    const int el = d.enc_layers[e];
+    const int take = inp_len < cur ? inp_len : cur;
+    if (take < cur) push(OP_SLICE, cur, cur - take, take, cur);
+    int L = take;
+    for (int l = 0; l < el; ++l) {
+      push(OP_LAYER, L, 0, 0, L);
+      if (d.distil && l < el - 1) {
+        push(OP_DISTIL, L, 0, 0, L + 2);
+        L = (L + 1) / 2 + 1;
+      }
+    }
+    push(OP_NORM_APPEND, L, mem_rows, 0, L);
+    mem_rows += L;
+    cur = L;
+    inp_len /= 2;
+  }
+  a.n_ops = n;
+  a.n_ops2 = n2;
+  a.n_ops3 = n3;
+  a.mem_rows = mem_rows;
+}
+
+// "Large" models run on the one-wave shape with three row tiles and / or six head pairs: more
+// than 8 heads, or more than 32 rows somewhere (the conv of a distil step adds two).
+static bool large_model(const cet_informer_cfg& c, const Dims& d) {
+  KArgs a{};
+  encoder_steps(d, a);
+  return head_pairs(c) > 4 || a.n_ops3 > 0 || d.seq_len > 32 || d.label_len + d.pred_len > 32;
+}
 
 static bool supported(const cet_informer_cfg& c) {
   // models run zero-padded to the kernels' 64 features and 8 or 12 heads of 8 features (widen())
@@ -1504,6 +1550,12 @@ static int qk_row(int p) {
   return 16 * t + 8 * (i >> 1) + 2 * g + (i & 1);
 }
 
+// The inverse: feature f of a query / key projection sits at output position qk_pos(f).
+static int qk_pos(int f) {
+  const int t = f >> 4, r = f & 15;
+  return 16 * t + 4 * ((r >> 1) & 3) + 2 * (r >> 3) + (r & 1);
+}
+
 // [out][in][3] (PyTorch Conv1d) -> [3][out][in]
 static void conv_taps_major(const float* src, int cout, int cin, std::vector<float>& dst) {
   for (int j = 0; j < 3; ++j)
@@ -1517,7 +1569,9 @@ static void conv_taps_major(const float* src, int cout, int cin, std::vector<flo
 // biases, LayerNorm and BatchNorm scales are zero (BatchNorm variance one), so padded features
 // are exactly zero everywhere; LayerNorm and the attention scale take the real sizes from the
 // kernel arguments. A 64-wide model with 8 heads of 8 comes out as it went in.
-static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const float* p) {
+// qk_permuted (large models, whose kernels keep the queries in registers): the output rows of
+// every query and key projection are stored in the order of qk_row().
+static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const float* p, bool qk_permuted) {
   const int D = c.d_model, F = c.d_ff, E = D / c.n_heads, HE = E * c.n_heads;
   const int HQ = 16 * head_pairs(c);
   std::vector<float> v;
@@ -1541,8 +1595,14 @@ static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const 
   };
   auto attn = [&]() {
     for (int k = 0; k < 3; ++k) {
-      mat(HE, D, 1, HQ, DM, head, ident);
-      vec(HE, head, 0.f, HQ);
+      if (qk_permuted && k < 2) {
+        auto hq = [&](int i) { return qk_pos(head(i)); };
+        mat(HE, D, 1, HQ, DM, hq, ident);
+        vec(HE, hq, 0.f, HQ);
+      } else {
+        mat(HE, D, 1, HQ, DM, head, ident);
+        vec(HE, head, 0.f, HQ);
+      }
     }
     mat(D, HE, 1, DM, HQ, ident, head);
     vec(D, ident);
@@ -1602,7 +1662,8 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   const cet_informer_cfg* c = c_in;
   const int NHP = head_pairs(*c_in);
   const size_t HQ = 16 * NHP;
-  const std::vector<float> wide = widen(*c_in, d, wsrc_in);
+  const bool large = large_model(*c_in, d);
+  const std::vector<float> wide = widen(*c_in, d, wsrc_in, large);
   const float* wsrc = wide.data();
   const size_t n = wide.size();
 
@@ -1626,7 +1687,7 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   // qk: the block is a query or key projection, whose output rows the workgroup kernel wants in
   // the order of qk_row() (see attention<.., QREG>).
   std::vector<float> blk;
-  const bool staged = NHP == 4;  // the workgroup kernel serves the 8-head family only
+  const bool staged = !large;  // the workgroup kernel serves the 8-head family of up to 30 slots only
   auto add_block = [&](const float* lin, const float* norm, bool qk = false) {
     if (!staged) return;
     const size_t base = blk.size();
@@ -1715,6 +1776,7 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   if (!m) return CET_ERR_ALLOC;
   m->cfg = *c_in;
   m->d = d;
+  m->large = large;
   for (int i = 0; i < d.n_attn; ++i) m->attn_per_sample += (size_t)c_in->n_heads * d.attn_len[i] * d.attn_len[i];
   for (int i = 0; i < d.n_taps; ++i) m->taps_per_sample += (size_t)d.tap_rows[i] * DM;
   m->n_blocks = (int)(blk.size() / WBLK);
@@ -1769,36 +1831,9 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   a.n_enc = m->d.n_enc; a.distil = m->d.distil; a.activation = m->d.activation;
   a.d_layers = m->d.d_layers;
   for (int i = 0; i < 8; ++i) a.enc_layers[i] = m->d.enc_layers[i];
-  // Steps of the encoder stack (encoder.py:87-101).
   {
-    int n = 0, cur = m->d.seq_len, inp_len = m->d.seq_len, mem_rows = 0, n2 = 0, n3 = 0;
-    auto push = [&](int type, int L, int p, int q, int need) {
-      a.ops[n] = Op{(unsigned char)type, (unsigned char)L, (unsigned char)p, (unsigned char)q};
-      if (need > 16) n2 = n + 1;
-      if (need > 32) n3 = n + 1;
-      ++n;
-    };
-    for (int e = 0; e < m->d.n_enc; ++e) {
-      const int el = m->d.enc_layers[e];
-      const int take = inp_len < cur ? inp_len : cur;
-      if (take < cur) push(OP_SLICE, cur, cur - take, take, cur);
-      int L = take;
-      for (int l = 0; l < el; ++l) {
-        push(OP_LAYER, L, 0, 0, L);
-        if (m->d.distil && l < el - 1) {
-          push(OP_DISTIL, L, 0, 0, L + 2);
-          L = (L + 1) / 2 + 1;
-        }
-      }
-      push(OP_NORM_APPEND, L, mem_rows, 0, L);
-      mem_rows += L;
-      cur = L;
-      inp_len /= 2;
-    }
-    a.n_ops = n;
-    a.n_ops2 = n2;
-    a.n_ops3 = n3;
-    a.mem_rows = mem_rows;
+    encoder_steps(m->d, a);
+    const int n = a.n_ops, n2 = a.n_ops2;
     // Packed tail of the step list: from the first step on after which every layer and distil
     // step has at most 8 rows per sequence and nothing is sliced.
     int p0 = n;
@@ -1822,7 +1857,7 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   // "large": three row tiles somewhere or six head pairs; one-wave shape, one instantiation per
   // head-pair count with three decoder and two memory tiles (padded tiles hold finite rows).
   const int NHP = head_pairs(m->cfg);
-  const bool large = NHP > 4 || a.n_ops3 > 0 || m->d.seq_len > 32 || Ld > 32;
+  const bool large = m->large;
   if (large && R < 24) R = 24;  // padded key tiles are read up to row 47 of the K | V regions
   a.region_rows = R;
   a.n_heads = m->cfg.n_heads;
@@ -1879,7 +1914,10 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     else CET_LAUNCH_WG(2, 2);
 #undef CET_LAUNCH_WG
   } else {
-    a.wave_lds_floats = 3 * R * (16 * NHP + (LDW - 64));
+    // Q | K | V regions, K | V for the large shapes (queries in registers); either also covers
+    // the conv / max-pool staging of 2 R + 2 rows of LDW floats
+    a.wave_lds_floats = (large ? 2 : 3) * R * (16 * NHP + (LDW - 64));
+    if (a.wave_lds_floats < (2 * R + 2) * LDW) a.wave_lds_floats = (2 * R + 2) * LDW;
     const size_t lds = (size_t)a.wave_lds_floats * sizeof(float);
     if (lds > 64 * 1024) return CET_ERR_UNSUPPORTED;  // cannot happen within supported()'s limits
     const dim3 grid((unsigned)B), block(64);
