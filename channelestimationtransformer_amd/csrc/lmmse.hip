@@ -26,6 +26,7 @@
 // on the expanded H.
 // With S = no*I the kernel uses A' = H^H H + no*I, for which d = 1 - no*(A'^-1)_ss and
 // no_eff = t/(1-t), t = no*(A'^-1)_ss: no cancellation in no_eff at high SNR.
+#include <cstdint>
 #include <cstdlib>
 
 #include <atomic>
@@ -1203,6 +1204,7 @@ static int grid_dispatch(const float* y, const float* h_hat, const float* err_va
                          float* x_hat, float* no_eff, int B, int n_sym, int fft, int n_sc, int n_ds,
                          hipStream_t stream) {
   const long n = (long)B * n_ds * n_sc;
+  // (two subcarriers per thread with 16-byte accesses run at the same 5.0 TB/s: not kept)
   const dim3 block(256), grid((unsigned)((n + 255) / 256));
 #define CET_GRID(NOISE, EV)                                                                      \
   hipLaunchKernelGGL((lmmse_grid<NR, NS, NOISE, EV>), grid, block, 0, stream,                     \

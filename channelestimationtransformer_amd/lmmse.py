@@ -61,6 +61,17 @@ def lmmse_llr(y, H, no, h_share=1):
                                    int(h_share))
 
 
+def _host_scalar(v):
+    """float(v) for Python / numpy numbers and 0-d CPU tensors, None for anything else."""
+    if isinstance(v, (int, float, np.integer, np.floating)):
+        return float(v)
+    if isinstance(v, np.ndarray) and v.ndim == 0:
+        return float(v)
+    if torch.is_tensor(v) and v.dim() == 0 and v.device.type == "cpu":
+        return float(v)
+    return None
+
+
 class StreamManagement:
     """Which streams go to which receiver. Carries `rx_tx_association` and
     `num_streams_per_tx` like the reference's `StreamManagement(np.array([[1]]), n)`
@@ -164,16 +175,25 @@ class LMMSEEqualizer:
         # the kernel reads both tensors where they are: [b, ant, sym, fft] and [b, ant, K, sym, sc]
         yv = torch.view_as_real(y.to(torch.complex64).contiguous()[:, 0])
         hv = torch.view_as_real(h_hat.to(torch.complex64).contiguous()[:, 0].reshape(b, ant, K, nsym, n_sc))
-        no_t = torch.as_tensor(no, dtype=torch.float32, device=dev)
-        ev = torch.as_tensor(err_var, dtype=torch.float32, device=dev)
-        extra = 0.0
-        if ev.dim() == 0:
-            extra = K * float(ev)  # the same variance on every stream's estimate
-            ev = torch.empty(0, dtype=torch.float32, device=dev)
+        # Scalars given as Python / numpy numbers stay on the host: a device copy read back with
+        # float() would synchronise with the GPU on every call.
+        no_h, ev_h = _host_scalar(no), _host_scalar(err_var)
+        empty = torch.empty(0, dtype=torch.float32, device=dev)
+        if ev_h is not None:
+            extra, ev = K * ev_h, empty  # the same variance on every stream's estimate
         else:
-            ev = torch.broadcast_to(ev, h_hat.shape)[:, 0].reshape(b, ant, K, nsym, n_sc).contiguous()
-        if no_t.dim() == 0:
-            mode, no_s, no_d = 0, float(no_t) + extra, torch.empty(0, dtype=torch.float32, device=dev)
+            ev = torch.as_tensor(err_var, dtype=torch.float32, device=dev)
+            if ev.dim() == 0:
+                extra, ev = K * ev, empty  # a device scalar: stays there
+            else:
+                extra = 0.0
+                ev = torch.broadcast_to(ev, h_hat.shape)[:, 0].reshape(b, ant, K, nsym, n_sc).contiguous()
+        no_t = None if no_h is not None else torch.as_tensor(no, dtype=torch.float32, device=dev)
+        if no_h is not None and not torch.is_tensor(extra):
+            mode, no_s, no_d = 0, no_h + extra, empty
+        elif no_t is None or no_t.dim() == 0:  # a device scalar somewhere: one value per batch entry
+            base = no_h if no_t is None else no_t
+            mode, no_s, no_d = 1, 0.0, (base + extra).reshape(1).expand(b).contiguous()
         elif no_t.numel() == b:
             mode, no_s, no_d = 1, 0.0, (no_t.reshape(b) + extra).contiguous()
         elif no_t.numel() == b * ant:

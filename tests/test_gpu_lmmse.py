@@ -207,6 +207,24 @@ def test_block_fading_equals_expanded_channel(Nr, Ns, N, h_share, kernel, oracle
         cet.lmmse(yt, Hbt[:-1] if nb > 1 else Ht[:0], 0.1, h_share=h_share)
 
 
+def test_equalizer_object_scalars_on_host_or_device():
+    """`no` and `err_var` as Python numbers (kept on the host: no synchronisation per call), as
+    0-d device tensors (kept on the device) and mixed give the same results."""
+    rg = cet.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=1,
+                          num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                          dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    equ = cet.LMMSEEqualizer(rg, cet.StreamManagement(np.array([[1]]), 2))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y = torch.view_as_complex(torch.randn(6, 1, 4, 14, 76, 2, device="cuda", generator=g))
+    h = torch.view_as_complex(torch.randn(6, 1, 4, 1, 2, 14, 64, 2, device="cuda", generator=g))
+    x0, n0 = equ([y, h, 0.02, 0.1])
+    dev = lambda v: torch.tensor(v, device="cuda")
+    for ev, no in ((dev(0.02), dev(0.1)), (0.02, dev(0.1)), (dev(0.02), 0.1), (np.float32(0.02), np.float64(0.1))):
+        x1, n1 = equ([y, h, ev, no])
+        assert torch.allclose(torch.view_as_real(x1), torch.view_as_real(x0), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(n1, n0, rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("Nr,Ns", [(16, 4), (16, 2), (16, 1), (8, 4), (8, 2), (4, 4), (4, 2), (2, 2), (2, 1)])
 def test_block_fading_staged_results_every_shape(Nr, Ns):
     """The shared-factorisation kernel collects a tile's results in LDS and stores them as whole
