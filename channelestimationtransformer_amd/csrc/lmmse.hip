@@ -323,10 +323,11 @@ __global__ __launch_bounds__(256) void lmmse_grid(const float2* __restrict__ y,
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const size_t at = ((plane * NS + k) * n_sym + sym) * n_sc + sc;
-      const float2 v = h_hat[at];
+      // the estimates are read exactly once, in whole lines: nontemporal
+      const float2 v = make_float2(__builtin_nontemporal_load(&h_hat[at].x), __builtin_nontemporal_load(&h_hat[at].y));
       hr[k] = v.x;
       hi[k] = v.y;
-      if (ERRVAR) ev += err_var[at];
+      if (ERRVAR) ev += __builtin_nontemporal_load(err_var + at);
     }
     gram_row<NS, WEIGHTED>(g, hr, hi, yv.x, yv.y, WEIGHTED ? 1.0f / (no_r + ev) : 1.0f);
   }
@@ -352,26 +353,51 @@ __global__ __launch_bounds__(256) void lmmse_grid(const float2* __restrict__ y,
 __device__ inline unsigned lds_address(const void* p) {
   return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
 }
+// NT: with the nontemporal hint, for operands whose 128-byte lines are read exactly once (a bare
+// stream of 16 KiB tiles reads 7.2 instead of 6.3 TB/s with it, tools/probe/stream.hip). Lines
+// that a later stage reads again (received vectors of fewer than 128 bytes) must not carry it:
+// they would come from HBM twice.
+#ifndef CET_DMA_NT
+#define CET_DMA_NT 1  // 0: timing experiment without the hint anywhere
+#endif
+template <bool NT = true>
 __device__ inline void dma16(const void* src, unsigned lds_addr_wave_uniform) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_addr_wave_uniform)
-      : "memory");
+  if (NT && CET_DMA_NT)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr_wave_uniform)
+        : "memory");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr_wave_uniform)
+        : "memory");
 }
 // The same with the source as a wave-uniform base (scalar registers) plus a 32-bit offset per lane:
 // no 64-bit vector arithmetic per instruction.
+template <bool NT = true>
 __device__ inline void dma16_base(const void* base_wave_uniform, unsigned lane_offset,
                                   unsigned lds_addr_wave_uniform) {
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(lane_offset), "s"(base_wave_uniform), "s"(lds_addr_wave_uniform)
-      : "memory");
+  if (NT && CET_DMA_NT)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_offset), "s"(base_wave_uniform), "s"(lds_addr_wave_uniform)
+        : "memory");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_offset), "s"(base_wave_uniform), "s"(lds_addr_wave_uniform)
+        : "memory");
 }
 __device__ inline void dma4(const void* src, unsigned lds_addr_wave_uniform) {
   unsigned keep;
@@ -772,6 +798,10 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
   constexpr int RPP = NR / LPR;
   static_assert(H_TILE % 1024 == 0 && Y_SYM % 1024 == 0, "stages are whole DMA instructions");
   static_assert(RPP % 2 == 0, "a lane reads y two antennas at a time");
+  // A stage brings GS * YB bytes of a block's received vectors; with fewer than 8 antennas a
+  // 128-byte line is shared by two or more stages (measured with the hint on every DMA: 4x2
+  // 0.043 -> 0.072 ms per 4.2 M REs, on the matrices alone 0.046; 16x2 0.146 -> 0.126).
+  constexpr bool STREAM_NT = NR >= 8;
 
   __shared__ __attribute__((aligned(16))) char smem[CET_BLOCK_GM * H_TILE];
   // stage_out: the results of a tile (T blocks x hs symbols: one contiguous range of x_hat and one
@@ -822,7 +852,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
         for (int i = 0; i < H_INSTR; ++i) {
           const int P = i * 64 + lane;
           const int tt = P / CH, q = P % CH;
-          dma16_base(base, (unsigned)(tt * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4)), dst + i * 1024);
+          dma16_base<STREAM_NT>(base, (unsigned)(tt * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4)), dst + i * 1024);
         }
         return;
       }
@@ -832,8 +862,8 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
         const int tt = P / CH, q = P % CH;
         long blk = blk0 + tt;
         blk = blk < n_blocks ? blk : n_blocks - 1;  // tail tile: re-read the last block
-        dma16(reinterpret_cast<const char*>(H) + blk * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4),
-              dst + i * 1024);
+        dma16<STREAM_NT>(reinterpret_cast<const char*>(H) + blk * HB + ((q ^ chunk_swizzle<CH>(tt)) << 4),
+                    dst + i * 1024);
       }
     } else {
       const int k0 = (st - 1) * GS;
@@ -843,7 +873,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
           if (whole) {
             const char* base = reinterpret_cast<const char*>(y) + (blk0 * hs + k0 + j) * YB;
 #pragma unroll
-            for (int i = 0; i < YS_INSTR; ++i) dma16_base(base, yoff[i], dst + (j * YS_INSTR + i) * 1024);
+            for (int i = 0; i < YS_INSTR; ++i) dma16_base<STREAM_NT>(base, yoff[i], dst + (j * YS_INSTR + i) * 1024);
             continue;
           }
 #pragma unroll
@@ -852,8 +882,8 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
             const int tt = P / CY, q = P % CY;
             long re = (blk0 + tt) * hs + k0 + j;
             re = re < N ? re : N - 1;  // ragged end: results of these lanes are not stored
-            dma16(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
-                  dst + (j * YS_INSTR + i) * 1024);
+            dma16<STREAM_NT>(reinterpret_cast<const char*>(y) + re * YB + ((q ^ chunk_swizzle<CY>(tt)) << 4),
+                        dst + (j * YS_INSTR + i) * 1024);
           }
         }
       }

@@ -4,30 +4,42 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// grid-stride plain loads, UNROLL independent 1 KiB wave loads in flight per wave
-template <int UNROLL>
+// grid-stride plain loads, UNROLL independent 1 KiB wave loads in flight per wave. NT: with the
+// nontemporal hint. TILED: a wave's UNROLL loads cover one contiguous tile (as the DMA kernels'
+// do) instead of UNROLL places a grid stride apart.
+template <int UNROLL, bool NT = true, bool TILED = false>
 __global__ __launch_bounds__(256) void plain(const f32x4* __restrict__ src, float* out, long n16) {
   const long stride = (long)gridDim.x * blockDim.x;
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) / 64, lane = threadIdx.x & 63;
+  long i = TILED ? wave * (64 * UNROLL) + lane : (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long ustep = TILED ? 64 : stride;
   f32x4 acc{0, 0, 0, 0};
-  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+  for (; i + (UNROLL - 1) * ustep < n16; i += UNROLL * stride) {
     f32x4 v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+    for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * ustep) : src[i + u * ustep];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) acc += v[u];
   }
   if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.f) out[0] = 1;
 }
 
+template <bool NT = false>
 __device__ inline void dma16(const void* src, unsigned lds) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
 }
 // one wave per block, tiles of TILE_KB, two buffers; SWZ: XOR the 16-byte chunk index inside
 // each 512-byte record with the record number (the LMMSE kernel's source permutation)
-template <int TILE_KB, bool SWZ, bool CONTIG, int WR = 0>
+// NT: nontemporal hint on the DMA. FRONT: instruction i of a "tile" reads 1 KiB at
+// i * (bytes / TILE_KB) + tile * 1 KiB: the waves of the grid advance TILE_KB fronts together, as
+// the plain-load kernel above does.
+template <int TILE_KB, bool SWZ, bool CONTIG, int WR = 0, bool NT = false, bool FRONT = false>
 __global__ __launch_bounds__(64) void dma(const char* __restrict__ src, float* out, long n_tiles, f32x4* wdst = nullptr) {
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE_KB * 1024];
   const int lane = threadIdx.x;
@@ -44,7 +56,10 @@ __global__ __launch_bounds__(64) void dma(const char* __restrict__ src, float* o
   const long step = CONTIG ? 1 : gridDim.x;
   auto fill = [&](int buf, long t) {
 #pragma unroll
-    for (int i = 0; i < TILE_KB; ++i) dma16(src + t * (TILE_KB * 1024L) + off[i], base + buf * TILE_KB * 1024 + i * 1024);
+    for (int i = 0; i < TILE_KB; ++i) {
+      if (FRONT) dma16<NT>(src + (i * n_tiles + t) * 1024L + lane * 16, base + buf * TILE_KB * 1024 + i * 1024);
+      else dma16<NT>(src + t * (TILE_KB * 1024L) + off[i], base + buf * TILE_KB * 1024 + i * 1024);
+    }
   };
   float acc = 0;
   int buf = 0;
@@ -99,6 +114,12 @@ int main() {
   timeit("plain loads, 4096 blocks x 256, unroll 8", [&] { plain<8><<<4096, 256>>>((const f32x4*)src, out, n16); }, bytes);
   timeit("plain loads, 1024 blocks x 256, unroll 16", [&] { plain<16><<<1024, 256>>>((const f32x4*)src, out, n16); }, bytes);
   timeit("plain loads, 1024 blocks x 64 (1 wave/SIMD), unroll 16", [&] { plain<16><<<1024, 64>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("plain loads, 1024 x 64, unroll 16, no nt hint", [&] { plain<16, false><<<1024, 64>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("plain loads, 1024 x 64, unroll 16, contiguous 16 KiB per wave", [&] { plain<16, true, true><<<1024, 64>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("plain loads, 1024 x 64, unroll 16, contiguous, no nt hint", [&] { plain<16, false, true><<<1024, 64>>>((const f32x4*)src, out, n16); }, bytes);
+  timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, strided, nt hint", [&] { dma<16, false, false, 0, true><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
+  timeit("LDS-DMA 16 x 1 KiB on 16 fronts x2, 1024 waves", [&] { dma<16, false, false, 0, false, true><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
+  timeit("LDS-DMA 16 x 1 KiB on 16 fronts x2, 1024 waves, nt hint", [&] { dma<16, false, false, 0, true, true><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
   timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, strided tiles", [&] { dma<16, false, false><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
   timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, strided, swizzled src", [&] { dma<16, true, false><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
   timeit("LDS-DMA 16 KiB tiles x2, 1024 waves, contiguous per wave", [&] { dma<16, false, true><<<1024, 64>>>(src, out, bytes / 16384); }, bytes);
@@ -106,6 +127,9 @@ int main() {
   hipMalloc(&wd, bytes / 2);
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 1 KiB store per tile (6%)", [&] { dma<16, false, false, 1><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 1 KiB nt store per tile", [&] { dma<16, false, false, 10><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
+  timeit("LDS-DMA nt 16 KiB x2, 1024 waves + 1 KiB store per tile (6%)", [&] { dma<16, false, false, 1, true><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
+  timeit("LDS-DMA nt 16 KiB x2, 1024 waves + 1 KiB nt store per tile", [&] { dma<16, false, false, 10, true><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (17.0 / 16));
+  timeit("LDS-DMA nt 16 KiB x2, 1024 waves + 4 KiB store per tile (25%)", [&] { dma<16, false, false, 4, true><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (20.0 / 16));
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 2 KiB store per tile (12%)", [&] { dma<16, false, false, 2><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (18.0 / 16));
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 4 KiB store per tile (25%)", [&] { dma<16, false, false, 4><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (20.0 / 16));
   timeit("LDS-DMA 16 KiB x2, 1024 waves + 6 KiB store per tile (37%)", [&] { dma<16, false, false, 6><<<1024, 64>>>(src, out, bytes / 16384, wd); }, bytes * (22.0 / 16));
