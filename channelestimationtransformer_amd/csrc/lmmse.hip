@@ -337,8 +337,10 @@ __global__ __launch_bounds__(256) void lmmse_grid(const float2* __restrict__ y,
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const size_t at = ((size_t)b * NS + k) * per_b + d;
-    x_hat[at] = make_float2(xr[k], xi[k]);
-    no_eff[at] = ne[k];
+    // whole lines per wave, written once: nontemporal (0.18 -> 0.14 ms per 8192 slots of 4x2)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(v2f{xr[k], xi[k]}, reinterpret_cast<v2f*>(x_hat + at));
+    __builtin_nontemporal_store(ne[k], no_eff + at);
   }
 }
 
@@ -1036,7 +1038,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
     const int xb = (int)n_re * NS * 8, nb = llr_mode ? 0 : (int)n_re * NS * 4;
     char* xg = reinterpret_cast<char*>(x_hat) + re0 * NS * 8;
     for (int o = lane * 16; o < xb; o += 1024)
-      *reinterpret_cast<v4f*>(xg + o) = *reinterpret_cast<const v4f*>(out_stage + o);
+      __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(out_stage + o), reinterpret_cast<v4f*>(xg + o));
     if (nb) {
       char* ng = reinterpret_cast<char*>(no_eff) + re0 * NS * 4;
       const float* nsrc = reinterpret_cast<const float*>(ne_stage);
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
 #pragma unroll
           for (int s2 = 0; s2 < NS; ++s2) v[r * NS + s2] = nsrc[blk * NS + s2];
         }
-        *reinterpret_cast<v4f*>(ng + o) = v4f{v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(v4f{v[0], v[1], v[2], v[3]}, reinterpret_cast<v4f*>(ng + o));
       }
     }
     return (xb + 1023) / 1024 + (nb + 1023) / 1024;

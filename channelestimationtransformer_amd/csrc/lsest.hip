@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void ls_nn_kernel(const float2* __restrict__ y
 }
 
 // Even T and 16-byte aligned outputs: a thread takes two neighbouring table entries, which it
-// reads once, for PL consecutive planes; 16-byte stores of h_hat and 8-byte stores of err_var
-// (one element and one plane per thread with its 8- and 4-byte stores wrote at 2.6 TB/s).
+// reads once, for PL consecutive planes; nontemporal 16-byte stores of h_hat and 8-byte stores of
+// err_var. Stores per launch of 8192 slots (705 MB): one element and one plane per thread with 8-
+// and 4-byte stores 0.27 ms, this shape with cached stores 0.18 ms, nontemporal 0.12 ms.
 // Threads are numbered over (plane group, entry pair) so that no block is partly empty.
 constexpr int LS_PL = 4;
 __global__ __launch_bounds__(256) void ls_nn_pairs(const float2* __restrict__ y,
@@ -67,9 +68,12 @@ __global__ __launch_bounds__(256) void ls_nn_pairs(const float2* __restrict__ y,
   for (int k = 0; k < LS_PL; ++k) {
     if (k < np) {
       const size_t at = (size_t)(p0 + k) * pairs + j;
-      h_hat[at] = make_float4(v0[k].x * q.x - v0[k].y * q.y, v0[k].x * q.y + v0[k].y * q.x,
-                              v1[k].x * q.z - v1[k].y * q.w, v1[k].x * q.w + v1[k].y * q.z);
-      err_var[at] = ev;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const v4f hv{v0[k].x * q.x - v0[k].y * q.y, v0[k].x * q.y + v0[k].y * q.x,
+                   v1[k].x * q.z - v1[k].y * q.w, v1[k].x * q.w + v1[k].y * q.z};
+      __builtin_nontemporal_store(hv, reinterpret_cast<v4f*>(h_hat + at));
+      __builtin_nontemporal_store(v2f{ev.x, ev.y}, reinterpret_cast<v2f*>(err_var + at));
     }
   }
 }
