@@ -171,6 +171,30 @@ def test_ls_estimator_nearest_neighbour(oracle):
     assert x_hat.shape == (b, 1, 2, 12 * 64) and torch.isfinite(no_eff).all()
 
 
+@pytest.mark.parametrize("fft,guards,dc,n_sym,streams,pil,b,ant", [
+    (76, [5, 6], True, 14, 2, [2, 11], 5, 2),    # 10 planes: the last group of four is ragged
+    (15, [0, 0], False, 7, 1, [3], 3, 3),        # 105 table entries (odd): the general kernel
+    (24, [2, 1], True, 5, 2, [0], 1, 1),         # a single plane
+])
+def test_ls_estimator_kernel_forms(oracle, fft, guards, dc, n_sym, streams, pil, b, ant):
+    """The estimator runs a kernel that takes two table entries and four antenna planes per
+    thread when the table is even, and a general one otherwise: both against the brute-force
+    statement, with plane counts that are no multiple of four."""
+    rg = cet.ResourceGrid(num_ofdm_symbols=n_sym, fft_size=fft, subcarrier_spacing=15e3, num_tx=1,
+                          num_streams_per_tx=streams, cyclic_prefix_length=1, num_guard_carriers=guards,
+                          dc_null=dc, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=pil)
+    n_eff = rg.num_effective_subcarriers
+    est = cet.LSChannelEstimator(rg, interpolation_type="nn")
+    rng = np.random.default_rng(fft + b)
+    y = (rng.standard_normal((b, 1, ant, n_sym, fft)) + 1j * rng.standard_normal((b, 1, ant, n_sym, fft))).astype(np.complex64)
+    h_hat, err_var = est([torch.from_numpy(y).cuda(), 0.2])
+    assert h_hat.shape == err_var.shape == (b, 1, ant, 1, streams, n_sym, n_eff)
+    wh, wev = oracle.ls_nn_numpy(y[:, 0], rg.pilots.reshape(streams, len(pil), n_eff), rg.pilot_ofdm_symbol_indices,
+                                 rg.effective_subcarrier_ind, 0.2)
+    assert np.abs(h_hat.cpu().numpy().reshape(wh.shape) - wh).max() < 1e-5
+    assert np.abs(err_var.cpu().numpy().reshape(wev.shape) - wev).max() < 1e-6
+
+
 @pytest.mark.parametrize("Nr,Ns", [(16, 4), (8, 4), (4, 2), (2, 1)])
 @pytest.mark.parametrize("N,h_share", [(14 * 300, 14), (14 * 300 - 5, 14), (4099, 3), (1000, 1000),
                                        (77, 2000), (64, 1)])
