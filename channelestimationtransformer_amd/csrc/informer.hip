@@ -127,6 +127,24 @@ DEV gptr uniform(const float* p) {
 DEV f32x4 ld4(gptr p) {
   return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(p);
 }
+// Attention-map stores go through a buffer descriptor: the lanes that have nothing to store get
+// an offset beyond the buffer and the hardware drops their part, so a store is one instruction
+// with no exec-mask branch around it and no 64-bit address arithmetic (base and per-head offset
+// are scalar). Rows of a map are only 4-byte aligned; buffer stores of 16 bytes take that.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned MAP_DROP = 0x80000000u;  // beyond any map buffer, and + 16 kt + i does not wrap
+DEV void bst4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+DEV void bst1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+// The first n (wave-uniform, 0..3) floats of v.
+DEV void bst_n(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int n, f32x4 v) {
+  if (n > 0) bst1(r, voff, soff, v[0]);
+  if (n > 1) bst1(r, voff + 4, soff, v[1]);
+  if (n > 2) bst1(r, voff + 8, soff, v[2]);
+}
 
 // Sum / max over the four lane groups g (lanes c, c+16, c+32, c+48), result in all four.
 // v_permlane16_swap / v_permlane32_swap exchange 16- and 32-lane halves inside the VALU, so
@@ -529,6 +547,45 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
         if (pack_L) ok = (key >> 3) == (ln.c >> 3) && (key & 7) < pack_L;
         bias[kt][qt][i] = ok ? 0.f : -INFINITY;
       }
+  // Attention-map stores, prepared once per call: a descriptor over this sequence's maps of the
+  // layer and, per query tile, this lane's byte offset inside a head's [Lq][Lk] map (its query
+  // row, key 4 g of key tile 0), or MAP_DROP where the lane holds nothing of the map.
+  float* const mapb = amap ? amap : amap2;
+  const int map_hl = pack_L ? pack_L * pack_L : Lq * Lk;  // floats of one head's map
+  // bytes of this sequence's maps (packed tiles: up to the end of the second sequence's)
+  const unsigned map_delta = (pack_L && amap && amap2) ? (unsigned)(amap2 - amap) : 0u;
+  const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      mapb, 0, mapb ? (int)((map_delta + (unsigned)(ln.n_heads * map_hl)) * 4u) : 0, 0x00020000);
+  unsigned mfull[RQ][RK];  // 16-byte stores of whole key groups
+  unsigned mtail[RQ];      // plain tiles: the ragged end of a row (Lk & 3 floats of one key group)
+  unsigned mlo = MAP_DROP, mhi = MAP_DROP;  // packed tiles: lanes holding keys 0..3 / 4..7 of their row
+  const int tail_n = Lk & 3, tail_k = Lk & ~3;
+  if (mapb) {
+    if (pack_L) {
+      const int sq = ln.c >> 3, ql = ln.c & 7;
+      const unsigned delta = map_delta;  // the second sequence's maps lie behind the first's
+      const bool row = (ln.g >> 1) == sq && ql < pack_L && (sq ? amap2 != nullptr : amap != nullptr);
+      const unsigned off = ((unsigned)(ql * pack_L + 4 * (ln.g & 1)) + (sq ? delta : 0u)) * 4u;
+      mlo = row && !(ln.g & 1) ? off : MAP_DROP;
+      mhi = row && (ln.g & 1) ? off : MAP_DROP;
+#pragma unroll
+      for (int qt = 0; qt < RQ; ++qt) {
+        mtail[qt] = MAP_DROP;
+#pragma unroll
+        for (int kt = 0; kt < RK; ++kt) mfull[qt][kt] = row ? off : MAP_DROP;
+      }
+    } else {
+#pragma unroll
+      for (int qt = 0; qt < RQ; ++qt) {
+        const int query = 16 * qt + ln.c;
+        const unsigned off = (unsigned)(query * Lk + 4 * ln.g) * 4u;
+#pragma unroll
+        for (int kt = 0; kt < RK; ++kt)
+          mfull[qt][kt] = (query < Lq && 16 * kt + 4 * ln.g + 3 < Lk) ? off + 64u * kt : MAP_DROP;
+        mtail[qt] = (query < Lq && tail_n && 4 * ln.g == (tail_k & 15)) ? off + 64u * (tail_k >> 4) : MAP_DROP;
+      }
+    }
+  }
 #pragma unroll
   for (int hp0 = 0; hp0 < NHP; hp0 += NP) {
     f32x4 p[NP][2][RK][RQ];  // [pair][head of the pair][key tile][query tile]
@@ -639,33 +696,28 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
         for (int qt = 0; qt < RQ; ++qt) {
 #pragma unroll
           for (int kt = 0; kt < RK; ++kt) p[pi][hh][kt][qt] *= sum[pi][hh][qt];
-          const int query = 16 * qt + ln.c;
-          if (pack_L) {
-            // rows of a map are at most 8 floats here: single stores
-            float* mp = (ln.c >> 3) ? amap2 : amap;
-            const int ql = ln.c & 7;
-            if (mp && ql < pack_L && 2 * (hp0 + pi) + hh < ln.n_heads) {
-              float* row = mp + ((size_t)(2 * (hp0 + pi) + hh) * pack_L + ql) * pack_L;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int kl = 4 * ln.g + i - 8 * (ln.c >> 3);
-                if (kl >= 0 && kl < pack_L) row[kl] = p[pi][hh][0][qt][i];
-              }
-            }
-          } else if (amap && query < Lq && 2 * (hp0 + pi) + hh < ln.n_heads) {
-            // a lane's four consecutive keys go out as one 16-byte store (rows of the map are
-            // only 4-byte aligned; global memory takes unaligned vector stores), the ragged
-            // end of a row as single floats
-            float* row = amap + ((size_t)(2 * (hp0 + pi) + hh) * Lq + query) * Lk;
-#pragma unroll
-            for (int kt = 0; kt < RK; ++kt) {
-              const int key0 = 16 * kt + 4 * ln.g;
-              if (key0 + 3 < Lk) {
-                *reinterpret_cast<f32x4_u*>(row + key0) = p[pi][hh][kt][qt];
+          const int head = 2 * (hp0 + pi) + hh;
+          if (mapb && head < ln.n_heads) {
+            const unsigned hoff = (unsigned)(head * map_hl) * 4u;  // wave-uniform: the head's map
+            if (pack_L) {
+              // a lane holds keys 4 (g & 1) .. + 3 of its row of at most 8 floats
+              const f32x4 v = p[pi][hh][0][qt];
+              if (pack_L == 8) {
+                bst4(mrsrc, mfull[qt][0], hoff, v);
               } else {
+                if (pack_L >= 4) bst4(mrsrc, mlo, hoff, v);
+                else bst_n(mrsrc, mlo, hoff, pack_L, v);
+                bst_n(mrsrc, mhi, hoff, pack_L - 4, v);
+              }
+            } else {
+              // a lane's four consecutive keys go out as one 16-byte store, the ragged end of a
+              // row as single floats
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
-                  if (key0 + i < Lk) row[key0 + i] = p[pi][hh][kt][qt][i];
+              for (int kt = 0; kt < RK; ++kt) bst4(mrsrc, mfull[qt][kt], hoff, p[pi][hh][kt][qt]);
+              if (tail_n) {
+#pragma unroll
+                for (int kt = 0; kt < RK; ++kt)
+                  if ((tail_k >> 4) == kt) bst_n(mrsrc, mtail[qt], hoff, tail_n, p[pi][hh][kt][qt]);
               }
             }
           }
