@@ -139,11 +139,14 @@ DEV void bst4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
 DEV void bst1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
-// The first n (wave-uniform, 0..3) floats of v.
+// The first n (wave-uniform, 0..3) floats of v, as one store of 4, 8 or 12 bytes.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 DEV void bst_n(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int n, f32x4 v) {
-  if (n > 0) bst1(r, voff, soff, v[0]);
-  if (n > 1) bst1(r, voff + 4, soff, v[1]);
-  if (n > 2) bst1(r, voff + 8, soff, v[2]);
+  const u32x4 u = __builtin_bit_cast(u32x4, v);
+  if (n == 1) bst1(r, voff, soff, v[0]);
+  else if (n == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{u[0], u[1]}, r, voff, soff, 0);
+  else if (n == 3) __builtin_amdgcn_raw_buffer_store_b96(u32x3{u[0], u[1], u[2]}, r, voff, soff, 0);
 }
 
 // Sum / max over the four lane groups g (lanes c, c+16, c+32, c+48), result in all four.
