@@ -149,6 +149,43 @@ DEV void bst_n(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int n, f3
   else if (n == 3) __builtin_amdgcn_raw_buffer_store_b96(u32x3{u[0], u[1], u[2]}, r, voff, soff, 0);
 }
 
+// Attention maps of a packed tile (two sequences of pack_L <= 8 rows; amap / amap2: their maps of
+// this layer, null where a sequence does not exist): descriptor from the first existing map to
+// the end of the second, and this lane's byte offsets (or MAP_DROP): lane (c, g) holds keys
+// 4 (g & 1) .. + 3 of row c & 7 of sequence c >> 3, and only in the lane groups of its own sequence.
+struct PackedMapLanes {
+  unsigned all, lo, hi;  // every lane of a row / the lanes holding keys 0..3 / keys 4..7
+};
+DEV __amdgpu_buffer_rsrc_t packed_map_rsrc(float* amap, float* amap2, int pack_L, int n_heads) {
+  float* const base = amap ? amap : amap2;
+  const unsigned delta = (amap && amap2) ? (unsigned)(amap2 - amap) : 0u;
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, base ? (int)((delta + (unsigned)(n_heads * pack_L * pack_L)) * 4u) : 0,
+                                           0x00020000);
+}
+DEV PackedMapLanes packed_map_lanes(const float* amap, const float* amap2, int pack_L, const int c, const int g) {
+  const int sq = c >> 3, ql = c & 7;
+  const unsigned delta = (amap && amap2) ? (unsigned)(amap2 - amap) : 0u;  // the second sequence's maps lie behind the first's
+  const bool row = (g >> 1) == sq && ql < pack_L && (sq ? amap2 != nullptr : amap != nullptr);
+  const unsigned off = ((unsigned)(ql * pack_L + 4 * (g & 1)) + (sq ? delta : 0u)) * 4u;
+  return PackedMapLanes{row ? off : MAP_DROP, row && !(g & 1) ? off : MAP_DROP, row && (g & 1) ? off : MAP_DROP};
+}
+// One head's tile v of a packed map: whole rows of 8 as one 16-byte store per lane, shorter rows
+// as a store of keys 0..3 (or fewer) and one of keys 4..
+DEV void packed_map_put(__amdgpu_buffer_rsrc_t r, const PackedMapLanes ml, int head, int pack_L, f32x4 v) {
+  const unsigned hoff = (unsigned)(head * pack_L * pack_L) * 4u;  // wave-uniform: the head's map
+  if (pack_L == 8) {
+    bst4(r, ml.all, hoff, v);
+  } else {
+    if (pack_L >= 4) bst4(r, ml.lo, hoff, v);
+    else bst_n(r, ml.lo, hoff, pack_L, v);
+    bst_n(r, ml.hi, hoff, pack_L - 4, v);
+  }
+}
+// Floats of the LDS area through which the primary wave of a packed tile hands the tiles of its
+// attention maps (8 heads x 64 lanes x 4 floats) to its partner wave, which is idle and issues the
+// stores in its place (a store instruction costs the issuing wave 70-140 clocks).
+constexpr int MAP_STAGE_FLOATS = 8 * 64 * 4;
+
 // Sum / max over the four lane groups g (lanes c, c+16, c+32, c+48), result in all four.
 // v_permlane16_swap / v_permlane32_swap exchange 16- and 32-lane halves inside the VALU, so
 // the reductions of softmax and LayerNorm never take the LDS round trip of a ds_bpermute.
@@ -530,7 +567,7 @@ DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const Act& x) 
 template <int RQ, int RK, bool QREG, int NHP = 4>
 DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* Vb, int Lq,
                    int Lk, bool causal, const Lane ln, Act& ctx, float* amap,
-                   int pack_L = 0, float* amap2 = nullptr) {
+                   int pack_L = 0, float* amap2 = nullptr, float* map_stage = nullptr) {
   constexpr int LDQ = ldq<NHP>();
   // head pairs per group (a divisor of NHP)
   constexpr int NP = (RQ * RK == 1) ? (NHP % 4 == 0 ? 4 : 2) : (RQ * RK == 2 ? 2 : 1);
@@ -555,28 +592,16 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
   // row, key 4 g of key tile 0), or MAP_DROP where the lane holds nothing of the map.
   float* const mapb = amap ? amap : amap2;
   const int map_hl = pack_L ? pack_L * pack_L : Lq * Lk;  // floats of one head's map
-  // bytes of this sequence's maps (packed tiles: up to the end of the second sequence's)
-  const unsigned map_delta = (pack_L && amap && amap2) ? (unsigned)(amap2 - amap) : 0u;
-  const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      mapb, 0, mapb ? (int)((map_delta + (unsigned)(ln.n_heads * map_hl)) * 4u) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrsrc =
+      pack_L ? packed_map_rsrc(amap, amap2, pack_L, ln.n_heads)
+             : __builtin_amdgcn_make_buffer_rsrc(mapb, 0, mapb ? ln.n_heads * map_hl * 4 : 0, 0x00020000);
   unsigned mfull[RQ][RK];  // 16-byte stores of whole key groups
-  unsigned mtail[RQ];      // plain tiles: the ragged end of a row (Lk & 3 floats of one key group)
-  unsigned mlo = MAP_DROP, mhi = MAP_DROP;  // packed tiles: lanes holding keys 0..3 / 4..7 of their row
+  unsigned mtail[RQ];      // the ragged end of a row (Lk & 3 floats of one key group)
+  PackedMapLanes mpk{MAP_DROP, MAP_DROP, MAP_DROP};
   const int tail_n = Lk & 3, tail_k = Lk & ~3;
   if (mapb) {
     if (pack_L) {
-      const int sq = ln.c >> 3, ql = ln.c & 7;
-      const unsigned delta = map_delta;  // the second sequence's maps lie behind the first's
-      const bool row = (ln.g >> 1) == sq && ql < pack_L && (sq ? amap2 != nullptr : amap != nullptr);
-      const unsigned off = ((unsigned)(ql * pack_L + 4 * (ln.g & 1)) + (sq ? delta : 0u)) * 4u;
-      mlo = row && !(ln.g & 1) ? off : MAP_DROP;
-      mhi = row && (ln.g & 1) ? off : MAP_DROP;
-#pragma unroll
-      for (int qt = 0; qt < RQ; ++qt) {
-        mtail[qt] = MAP_DROP;
-#pragma unroll
-        for (int kt = 0; kt < RK; ++kt) mfull[qt][kt] = row ? off : MAP_DROP;
-      }
+      if (!map_stage) mpk = packed_map_lanes(amap, amap2, pack_L, ln.c, ln.g);
     } else {
 #pragma unroll
       for (int qt = 0; qt < RQ; ++qt) {
@@ -703,15 +728,9 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
           if (mapb && head < ln.n_heads) {
             const unsigned hoff = (unsigned)(head * map_hl) * 4u;  // wave-uniform: the head's map
             if (pack_L) {
-              // a lane holds keys 4 (g & 1) .. + 3 of its row of at most 8 floats
-              const f32x4 v = p[pi][hh][0][qt];
-              if (pack_L == 8) {
-                bst4(mrsrc, mfull[qt][0], hoff, v);
-              } else {
-                if (pack_L >= 4) bst4(mrsrc, mlo, hoff, v);
-                else bst_n(mrsrc, mlo, hoff, pack_L, v);
-                bst_n(mrsrc, mhi, hoff, pack_L - 4, v);
-              }
+              // the tile goes to the partner wave, which stores it (partner_write_maps()), or out
+              if (map_stage) st4(map_stage + (head * 64 + 16 * ln.g + ln.c) * 4, p[pi][hh][0][qt]);
+              else packed_map_put(mrsrc, mpk, head, pack_L, p[pi][hh][0][qt]);
             } else {
               // a lane's four consecutive keys go out as one 16-byte store, the ragged end of a
               // row as single floats
@@ -818,7 +837,7 @@ template <int NHP> constexpr int sz_enc_layer() { return sz_attn<NHP>() + SZ_FFN
 template <int RT, bool WG, bool QR, int NHP>
 DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int R, const Lane ln,
                        int L, int activation, float* amap, Act& x, int pack_L = 0,
-                       float* amap2 = nullptr) {
+                       float* amap2 = nullptr, float* map_stage = nullptr) {
   constexpr int SZ_ATTN = sz_attn<NHP>();
   const float* nw = w + SZ_ATTN + SZ_FFN;
   WFrag A;
@@ -826,7 +845,7 @@ DEV void encoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
   Act t, y;
   project_qkv<RT, RT, WG, QR, NHP>(w, st, smem, R, ln, x, x, L, L, t);
   attention<RT, RT, QR, NHP>(t, region_q<QR, NHP>(smem, R), region_k<QR, NHP>(smem, R),
-                             region_v<QR, NHP>(smem, R), L, L, false, ln, y, amap, pack_L, amap2);
+                             region_v<QR, NHP>(smem, R), L, L, false, ln, y, amap, pack_L, amap2, map_stage);
   PROF_MARK(ln, P_ATTN);
   next_weights<WG, 4, NHP>(A, st, w + 3 * sz_qkv<NHP>(), ln, &n, nw);  // output projection, norm1
   wmul<RT, 4, NHP>(A, y, t);
@@ -1235,6 +1254,18 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
   }
 }
 
+// Rows 0..15 of a partner's region carry the rows exchanged between the two waves; the map tiles
+// follow (8 KiB of the 32 rows a packed region has beyond them).
+constexpr int MAP_STAGE_ROW = 16;
+static_assert(MAP_STAGE_FLOATS <= (48 - MAP_STAGE_ROW) * LDW, "map staging area exceeds a packed region");
+// The partner's side: stores heads [h0, h1) of the staged map tiles of a packed layer.
+DEV void partner_write_maps(const float* stage, float* amap, float* amap2, int L, const Lane ln, int h0, int h1) {
+  if (!amap && !amap2) return;
+  const __amdgpu_buffer_rsrc_t r = packed_map_rsrc(amap, amap2, L, ln.n_heads);
+  const PackedMapLanes ml = packed_map_lanes(amap, amap2, L, ln.c, ln.g);
+  if (h1 > ln.n_heads) h1 = ln.n_heads;
+  for (int h = h0; h < h1; ++h) packed_map_put(r, ml, h, L, ld4(stage + (h * 64 + 16 * ln.g + ln.c) * 4));
+}
 // One encoder step of the primary wave on a packed tile (sequences b and b2; b2 = -1: none).
 template <int RM>
 DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
@@ -1248,7 +1279,10 @@ DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float
       if (b2 >= 0) amap2 = cu.attn + (size_t)b2 * a.n_heads * L * L;
       cu.attn += (size_t)a.B * a.n_heads * L * L;
     }
-    encoder_layer<1, true, true, 4>(cu.w, st, smem, R, ln, 16, a.activation, amap, x, L, amap2);
+    // the tiles of the maps go to rows MAP_STAGE_ROW.. of the partner's region; the partner stores
+    // them once the staging barrier of the output projection has published them
+    encoder_layer<1, true, true, 4>(cu.w, st, smem, R, ln, 16, a.activation, amap, x, L, amap2,
+                                    partner_smem + MAP_STAGE_ROW * LDW);
     cu.w += sz_enc_layer<4>();
     tap_packed(cu.taps, a.B, b, b2, L, ln, x);
   } else if (op.type == OP_DISTIL) {
@@ -1267,12 +1301,29 @@ DEV void run_op_packed(const Op op, const KArgs& a, Cursor& cu, Stage& st, float
 }
 // The same step seen from the partner wave: it keeps its share of the weight staging and the
 // barriers, advances the cursors and collects its encoder outputs.
+// attn_all: the maps of the step's layer for all sequences (null: not wanted); b1 / b2: the
+// primary's and the own sequence (-1: beyond the batch).
 template <int RM>
 DEV void run_op_partner(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
-                        const Lane ln, Act& mem) {
+                        const Lane ln, Act& mem, float*& attn_all, int b1, int b2) {
   const int L = op.L;
   if (op.type == OP_LAYER) {
-    for (int k = 0; k < 6; ++k) stage_acquire(st);
+    float *amap = nullptr, *amap2 = nullptr;
+    if (attn_all) {
+      if (b1 >= 0) amap = attn_all + (size_t)b1 * a.n_heads * L * L;
+      if (b2 >= 0) amap2 = attn_all + (size_t)b2 * a.n_heads * L * L;
+      attn_all += (size_t)a.B * a.n_heads * L * L;
+    }
+    // blocks q k v | o conv1 conv2. The staging barrier of the output projection (every acquire
+    // but the packed phase's very first passes one) has the primary's map tiles in LDS; they
+    // are stored in three parts, so that the acknowledgements the next barrier's wait collects
+    // with the weight pieces do not make this wave late for it.
+    for (int k = 0; k < 6; ++k) {
+      stage_acquire(st);
+      if (k == 3) partner_write_maps(smem + MAP_STAGE_ROW * LDW, amap, amap2, L, ln, 0, 3);
+      if (k == 4) partner_write_maps(smem + MAP_STAGE_ROW * LDW, amap, amap2, L, ln, 3, 6);
+      if (k == 5) partner_write_maps(smem + MAP_STAGE_ROW * LDW, amap, amap2, L, ln, 6, 8);
+    }
     if (cu.attn) cu.attn += (size_t)a.B * a.n_heads * L * L;
     cu.w += sz_enc_layer<4>();
     if (cu.taps) cu.taps += (size_t)a.B * L * DM;
@@ -1395,7 +1446,14 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
       wave_sync();
       store_rows<1>(smem, ln, x, L0);
       exchange_barrier();
-      for (; i < a.n_ops; ++i) run_op_partner<RM>(a.ops[i], a, cu, st, smem, ln, mem);
+      // the maps of the next layer, for all sequences: behind those of the layers done so far
+      float* attn_all = a.attn;
+      if (attn_all)
+        for (int j = 0; j < i; ++j)
+          if (a.ops[j].type == OP_LAYER) attn_all += (size_t)a.B * a.n_heads * a.ops[j].L * a.ops[j].L;
+      const int seq1 = seq - WG_WAVES / 2;
+      for (; i < a.n_ops; ++i)
+        run_op_partner<RM>(a.ops[i], a, cu, st, smem, ln, mem, attn_all, seq1 < a.B ? seq1 : -1, valid ? b : -1);
     } else {
       float* partner_smem = smem + (WG_WAVES / 2) * a.wave_lds_floats;
       const int seq2 = seq + WG_WAVES / 2;
