@@ -1,5 +1,7 @@
 // C ABI of libcet.so (declared in include/cet.h): argument validation, status codes and the
 // handle type. The kernels and their launchers live in lmmse.hip, informer.hip and rnn.hip.
+#include <cstdint>
+#include <initializer_list>
 #include <new>
 
 #include "cet_internal.h"
@@ -197,6 +199,9 @@ static int lmmse_checked(const float* y, const float* H, int no_mode, float no_s
   if (!y || !H || !x_hat || (!llr && !no_eff)) return CET_ERR_INVALID_ARG;
   if (no_mode != CET_NO_SCALAR && !no_dev) return CET_ERR_INVALID_ARG;
   if (no_mode == CET_NO_SCALAR && !(no_scalar > 0.f)) return CET_ERR_INVALID_ARG;
+  // the kernels move 16-byte pieces (LDS-DMA, vector loads and stores)
+  for (const void* p : {(const void*)y, (const void*)H, (const void*)x_hat, (const void*)no_eff, (const void*)no_dev})
+    if (reinterpret_cast<uintptr_t>(p) & 15) return CET_ERR_INVALID_ARG;
   if (Ns > Nr) return CET_ERR_UNSUPPORTED;
   return lmmse_launch(y, H, no_mode, no_scalar, no_dev, x_hat, llr ? nullptr : no_eff, N, Nr, Ns,
                       h_share, variant, static_cast<hipStream_t>(stream));

@@ -1037,8 +1037,16 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
     const long n_re = N - re0 < (long)T * hs ? N - re0 : (long)T * hs;  // elements of this tile
     const int xb = (int)n_re * NS * 8, nb = llr_mode ? 0 : (int)n_re * NS * 4;
     char* xg = reinterpret_cast<char*>(x_hat) + re0 * NS * 8;
-    for (int o = lane * 16; o < xb; o += 1024)
-      __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(out_stage + o), reinterpret_cast<v4f*>(xg + o));
+    // xb is a multiple of 8 and nb of 4 only (one or two streams, ragged last tile): the piece
+    // that holds the end of the range is written float by float up to the range's last byte.
+    for (int o = lane * 16; o < xb; o += 1024) {
+      if (o + 16 <= xb) {
+        __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(out_stage + o), reinterpret_cast<v4f*>(xg + o));
+      } else {
+        for (int b = o; b < xb; b += 4)
+          *reinterpret_cast<float*>(xg + b) = *reinterpret_cast<const float*>(out_stage + b);
+      }
+    }
     if (nb) {
       char* ng = reinterpret_cast<char*>(no_eff) + re0 * NS * 4;
       const float* nsrc = reinterpret_cast<const float*>(ne_stage);
@@ -1054,7 +1062,13 @@ __global__ __launch_bounds__(64) void lmmse_block(const float* __restrict__ y,
 #pragma unroll
           for (int s2 = 0; s2 < NS; ++s2) v[r * NS + s2] = nsrc[blk * NS + s2];
         }
-        __builtin_nontemporal_store(v4f{v[0], v[1], v[2], v[3]}, reinterpret_cast<v4f*>(ng + o));
+        if (o + 16 <= nb) {
+          __builtin_nontemporal_store(v4f{v[0], v[1], v[2], v[3]}, reinterpret_cast<v4f*>(ng + o));
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (o + q * 4 < nb) *reinterpret_cast<float*>(ng + o + q * 4) = v[q];
+        }
       }
     }
     return (xb + 1023) / 1024 + (nb + 1023) / 1024;

@@ -32,7 +32,8 @@ def _f32(name, t, *shape):
         raise RuntimeError(f"{name} must be float32, got {t.dtype}")
     if t.dim() != len(shape) or any(s is not None and int(d) != int(s) for d, s in zip(t.shape, shape)):
         raise RuntimeError(f"{name} must have shape {list(shape)}, got {list(t.shape)}")
-    return t.contiguous()
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() % 16 else t  # a slice may start anywhere; the C ABI wants 16 B
 
 
 def _noise(no, no_mode, N, Nr):

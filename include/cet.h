@@ -186,7 +186,9 @@ enum {
  *   G = (H^H S^-1 H + I)^-1 H^H S^-1,  x_hat = diag(GH)^-1 G y,  no_eff = Re(1/diag(GH) - 1)
  * with S diagonal. Device pointers, interleaved (re,im) float32:
  *   y [N,Nr,2], H [N,Nr,Ns,2]  ->  x_hat [N,Ns,2], no_eff [N,Ns].
- * Supported (Nr,Ns): Nr in {2,4,8,16}, Ns in {1,2,4}, Ns <= Nr. */
+ * Supported (Nr,Ns): Nr in {2,4,8,16}, Ns in {1,2,4}, Ns <= Nr. Every device pointer of the
+ * LMMSE entry points must be 16-byte aligned (CET_ERR_INVALID_ARG otherwise); the kernels write
+ * exactly the N * Ns elements of each output and nothing behind them. */
 int cet_lmmse(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
               float* x_hat, float* no_eff, long N, int Nr, int Ns, void* stream);
 

@@ -222,3 +222,23 @@ def test_more_shipped_checkpoints(cell, tag, variant):
         want = v[f"{cell}_{tag}/pred{P}"]
         out = m.test_data(x, P, "cuda").cpu().numpy()
         assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "RNN"])
+def test_literal_4x4_mimo_configuration(cell, variant):
+    """GRU / LSTM / RNN(32, 32, 256, 2) on 64 histories of a 4x4 channel (32 real features),
+    pred_len 5 and 25, against the imported reference (tests/golden/make_golden_config1.py;
+    LocalSimulations/models/model.py:298-312, 373-388, 449-465). Weights: PyTorch's default
+    initialisation (no checkpoint of this shape ships with the reference)."""
+    v = load_npz("rnn_config1.npz")
+    m = getattr(cet, cell)(32, 32, 256, 2)
+    m.load_state_dict({k: torch.from_numpy(np.array(a)) for k, a in sub_dict(v, f"{cell}/sd").items()})
+    m.eval().select_kernel(variant)
+    x = torch.from_numpy(v["x"]).cuda()
+    assert tuple(x.shape) == (64, 25, 32)
+    for P in (5, 25):
+        want = v[f"{cell}/pred{P}"]
+        out = m.test_data(x, P, "cuda").cpu().numpy()
+        assert out.shape == want.shape == (64, P, 32)
+        assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))

@@ -183,6 +183,19 @@ def test_checker_on_the_pred_len_3_recurrent_checkpoints(cell, kind, oracle):
         assert np.abs(out - want).max() < 1e-5 * max(1.0, float(np.abs(want).max()))
 
 
+@pytest.mark.parametrize("cell,kind", [("GRU", 1), ("LSTM", 2), ("RNN", 0)])
+def test_checker_on_the_literal_4x4_mimo_configuration(cell, kind, oracle):
+    """GRU / LSTM / RNN(32, 32, 256, 2), 64 histories of 32 features, pred_len 5 and 25, against
+    the imported reference (tests/golden/make_golden_config1.py)."""
+    v = load_npz("rnn_config1.npz")
+    blob = blobs.pack_rnn(sub_dict(v, f"{cell}/sd"), kind, 32, 32, 256, 2)
+    for P in (5, 25):
+        want = v[f"{cell}/pred{P}"]
+        out = oracle.rnn_rollout(kind, 32, 32, 256, 2, blob, v["x"], P)
+        assert out.shape == want.shape == (64, P, 32)
+        assert np.abs(out - want).max() < 1e-5 * max(1.0, float(np.abs(want).max()))
+
+
 def nmse_db_per_slot(pred, truth):
     return 10 * np.log10(((truth - pred) ** 2).sum((0, 2)) / (truth ** 2).sum((0, 2)))
 
