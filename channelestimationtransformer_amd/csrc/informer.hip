@@ -1532,9 +1532,8 @@ struct InformerModel {
   int device = 0;  // the HIP device that holds the weights
   int cus = 0;     // its compute units
   // Launch shape: 0 = by batch size, 1 = one wave per sequence, 2 = workgroups of 8 sequences;
-  // pack = two sequences per tile in the short encoder stages of the workgroup kernel. Set at
-  // create time (CET_INFORMER_KERNEL / CET_INFORMER_PACK in the environment) or through
-  // cet_informer_select; never read from the environment in the launch path.
+  // pack = two sequences per tile in the short encoder stages of the workgroup kernel. Set
+  // through cet_informer_select only (the library reads no environment variables).
   int kernel_choice = 0;
   bool pack = true;
   bool large = false;  // large_model(): its query / key projections are stored row-permuted
@@ -1893,8 +1892,6 @@ int informer_create(const cet_informer_cfg* c_in, const float* wsrc_in, size_t n
   for (int i = 0; i < d.n_attn; ++i) m->attn_per_sample += (size_t)c_in->n_heads * d.attn_len[i] * d.attn_len[i];
   for (int i = 0; i < d.n_taps; ++i) m->taps_per_sample += (size_t)d.tap_rows[i] * DM;
   m->n_blocks = (int)(blk.size() / WBLK);
-  if (const char* k = getenv("CET_INFORMER_KERNEL")) m->kernel_choice = k[0] == 'o' ? 1 : (k[0] == 'w' ? 2 : 0);
-  if (const char* k = getenv("CET_INFORMER_PACK")) m->pack = k[0] != '0';
   hipError_t e = hipGetDevice(&m->device);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&m->cus, hipDeviceAttributeMultiprocessorCount, m->device);
   // the workgroup kernel's dynamic LDS exceeds the default limit: raised once per device, here

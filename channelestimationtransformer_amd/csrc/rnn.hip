@@ -23,6 +23,7 @@
 //     consumes that result from registers again. In the closed-loop phase nothing but the
 //     predictions ever goes to HBM.
 #include <cstdio>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -86,6 +87,9 @@ struct RArgs {
   const float* x;        // [B][seq][F]
   float* out;            // [B][pred][F]
   int B, seq_len, pred_len, F, IP;  // IP: encoder width padded to 16
+  // Conditional launch: when set, the workgroups return at once unless this word is non-zero (the
+  // failure flag of the hidden-split rollout launched just before on the same stream).
+  const unsigned* only_if;
   unsigned long long* prof;         // profiling build only
 };
 
@@ -205,6 +209,9 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
   constexpr int D = ring_depth(KIND);
   static_assert((H / 8) % D == 0, "segment lengths must be multiples of the ring depth");
 
+  if (a.only_if != nullptr &&
+      __hip_atomic_load(a.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+    return;  // uniform over the grid: the rollout this launch stands by for has succeeded
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -453,8 +460,19 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
 //   step ahead of the slowest one of its tile, so two buffers suffice.
 //   * the encoder and decoder Linears are small and computed redundantly by every workgroup, so
 //     the closed-loop feedback needs no further exchange.
-// The grid (tiles x H / 16 workgroups, one per CU) must be resident at once: the launcher only
-// picks this kernel while the grid fits the device's CU count.
+// Only the H / 16 workgroups of ONE sequence tile wait for each other, and the hardware starts a
+// grid's workgroups in index order (a tile's are consecutive), so a grid has at most one tile that
+// is partly resident; every complete tile runs to its end and frees its CUs. A wait can therefore
+// only fail to end while other work holds the CUs that the missing workgroups of a tile need:
+//   * other kernels that finish by themselves only delay it;
+//   * other hidden-split grids of this process are limited to SPLIT_SLOTS at a time per GPU (the
+//     pool of exchange buffers below), i.e. to SPLIT_SLOTS partly resident tiles, far below the CU
+//     count, so among them some tile is always complete;
+//   * whatever remains (grids of other processes, a co-resident kernel that runs for seconds) ends
+//     in the bounded wait: the grid drains, raises its failure flag, and the batch-tiled kernel,
+//     launched behind every hidden-split launch on the same stream and returning at once while
+//     the flag is down, computes the chunk instead. No path leaves a wrong result.
+// The launcher only picks this kernel while a launch's grid fits the device's CU count.
 constexpr int ST = 16;        // sequences per workgroup
 // Head of the scratch buffer (zeroed before every launch): arrival counters, one per tile and layer
 // (at most 32 tiles x 3 layers), each in a 128-byte line of its own (with all of them in one
@@ -482,6 +500,7 @@ struct SArgs {
   float* hx;             // exchange: [tile][layer][parity][unit group][256]
   unsigned* cnt;         // arrival counters [tile][layer], zero at launch
   int B, seq_len, pred_len, F, I;
+  int spin_limit;        // polls after which a wait gives up
 };
 
 template <int KIND, int H, int NL>
@@ -601,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
              (l2 >= 0 &&
               __hip_atomic_load(cnt_tile + l2 * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target2)) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > SPIN_LIMIT) {
+        if (++spins > a.spin_limit) {
           dead = 1;
           __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
@@ -840,14 +859,33 @@ struct RnnModel {
   const float *wstream, *bias, *enc_w, *enc_b, *dec_w, *dec_b;
   const float *w_ih[3], *w_hh[3];  // gate weights in their PyTorch layouts (hidden-split kernel)
   int device = 0, cus = 0;
-  int variant = 0;  // 0: by batch size, 1: batch-tiled kernel, 2: hidden-split kernel
-  // Exchange buffer of the hidden-split kernel: allocated by the first rollout that needs it (or
-  // a larger one), kept until the handle is destroyed. Rollouts of one handle that overlap in time
-  // share it and would race.
-  mutable float* scratch = nullptr;
-  mutable size_t scratch_bytes = 0;
+  // 0: by batch size, 1: batch-tiled kernel, 2: hidden-split kernel, 3: hidden-split kernel whose
+  // exchange gives up at its first unanswered poll (tests: exercises the stand-by launch)
+  int variant = 0;
   float* static_scratch = nullptr;  // device address of g_split_scratch on this handle's device
 };
+
+// Exchange buffers of the hidden-split kernel: SPLIT_SLOTS per GPU, shared by all handles on it,
+// allocated by the first rollout that needs one and kept until the process ends. A rollout claims
+// a slot for its launches and leaves an event behind them: the next claim takes the slot its own
+// stream used last (stream order protects it), else one whose event has completed, else makes its
+// stream wait for the oldest slot's event. Rollouts of any handles on any streams may therefore
+// overlap; at most SPLIT_SLOTS hidden-split grids are in flight per GPU.
+constexpr int SPLIT_SLOTS = 4;
+constexpr int SPLIT_MAX_DEVICES = 64;
+struct SplitSlot {
+  float* buf = nullptr;
+  hipEvent_t done = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;
+};
+struct SplitPool {
+  std::mutex mu;
+  SplitSlot slot[SPLIT_SLOTS];
+  size_t slot_bytes = 0;
+  unsigned next = 0;  // round robin over busy slots
+};
+static SplitPool g_split_pool[SPLIT_MAX_DEVICES];
 
 static int rnn_prepare(const RnnModel* m);  // per-device kernel attributes, defined with the launchers
 
@@ -865,7 +903,6 @@ static bool rnn_supported(int kind, int F, int I, int H, int layers) {
 void rnn_destroy(RnnModel* m) {
   if (!m) return;
   if (m->dev) (void)hipFree(m->dev);
-  if (m->scratch) (void)hipFree(m->scratch);
   delete m;
 }
 
@@ -976,7 +1013,6 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     rnn_destroy(m);
     return hip_fail(e);
   }
-  if (const char* k = getenv("CET_RNN_KERNEL")) m->variant = k[0] == 't' ? 1 : (k[0] == 's' ? 2 : 0);
   if (const int rc = rnn_prepare(m)) {
     rnn_destroy(m);
     return rc;
@@ -1068,11 +1104,21 @@ static bool split_fits(const RnnModel* m, int B, int max_wg) {
   return wg <= m->cus && wg <= max_wg;
 }
 
+static RArgs tiled_args(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len) {
+  RArgs a{};
+  a.wstream = m->wstream; a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b;
+  a.dec_w = m->dec_w; a.dec_b = m->dec_b; a.x = x; a.out = out;
+  a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F; a.IP = m->IP;
+  return a;
+}
+
 // The hidden-split rollout on `scratch` (device, SPLIT_CNT_FLOATS + tiles * layers * 2 * H / 16 *
-// 256 floats): zeroes the counters and launches. Allocates nothing.
+// 256 floats): zeroes the counters, launches, and launches the batch-tiled kernel behind it on
+// condition of the failure flag. Allocates nothing.
 static int rollout_split(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                          float* scratch, hipStream_t stream) {
   SArgs a{};
+  a.spin_limit = m->variant == 3 ? 0 : SPIN_LIMIT;
   for (int l = 0; l < 3; ++l) {
     a.w_ih[l] = m->w_ih[l];
     a.w_hh[l] = m->w_hh[l];
@@ -1083,11 +1129,55 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
   a.hx = scratch + SPLIT_CNT_FLOATS;
   CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
   const int tiles = split_tiles(B);
+  int rc;
   switch (m->kind) {
-    case CET_RNN_TANH: return launch_split_kind<CET_RNN_TANH>(m, a, tiles, stream);
-    case CET_RNN_GRU: return launch_split_kind<CET_RNN_GRU>(m, a, tiles, stream);
-    default: return launch_split_kind<CET_RNN_LSTM>(m, a, tiles, stream);
+    case CET_RNN_TANH: rc = launch_split_kind<CET_RNN_TANH>(m, a, tiles, stream); break;
+    case CET_RNN_GRU: rc = launch_split_kind<CET_RNN_GRU>(m, a, tiles, stream); break;
+    default: rc = launch_split_kind<CET_RNN_LSTM>(m, a, tiles, stream); break;
   }
+  if (rc != CET_OK) return rc;
+  RArgs t = tiled_args(m, x, out, B, seq_len, pred_len);
+  t.only_if = a.cnt + (SPLIT_CNT_FLOATS - 1);
+  PrepareFn pf;
+  LaunchFn lf;
+  if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
+  return lf(t, stream);
+}
+
+// Claims an exchange buffer of this device's pool for launches on `stream` (see SplitPool).
+static int split_claim(const RnnModel* m, hipStream_t stream, SplitPool** pool_out, int* slot_out) {
+  if (m->device < 0 || m->device >= SPLIT_MAX_DEVICES) return CET_ERR_UNSUPPORTED;
+  SplitPool& pool = g_split_pool[m->device];
+  const size_t need = (SPLIT_CNT_FLOATS + (size_t)m->cus * SPLIT_MAX_LAYERS * 2 * 256) * sizeof(float);
+  std::lock_guard<std::mutex> lock(pool.mu);
+  if (pool.slot_bytes < need) {  // first use on this device (the CU count of a device is fixed)
+    for (int i = 0; i < SPLIT_SLOTS; ++i) {
+      SplitSlot& sl = pool.slot[i];
+      if (!sl.buf) CET_HIP(hipMalloc(&sl.buf, need));
+      if (!sl.done) CET_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    pool.slot_bytes = need;
+  }
+  int pick = -1;
+  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i)
+    if (pool.slot[i].used && pool.slot[i].last == stream) pick = i;
+  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i)
+    if (!pool.slot[i].used) pick = i;
+  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i) {
+    const hipError_t q = hipEventQuery(pool.slot[i].done);
+    if (q == hipSuccess) pick = i;
+    else if (q != hipErrorNotReady) return hip_fail(q);
+  }
+  if (pick < 0) {  // all in flight on other streams: queue behind the one whose turn it is
+    pick = (int)(pool.next++ % SPLIT_SLOTS);
+    CET_HIP(hipStreamWaitEvent(stream, pool.slot[pick].done, 0));
+  }
+  // Owned by `stream` from here on; the event is recorded by split_release behind the launches.
+  pool.slot[pick].used = true;
+  pool.slot[pick].last = stream;
+  *pool_out = &pool;
+  *slot_out = pick;
+  return CET_OK;
 }
 
 int rnn_device(const RnnModel* m) { return m->device; }
@@ -1115,28 +1205,37 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   const int chunk = split_chunk(m);
   const int n_chunks = chunk > 0 ? (B + chunk - 1) / chunk : 0;
   const int max_chunks = m->kind == CET_RNN_TANH ? 4 : (m->kind == CET_RNN_GRU ? 7 : 9);
-  if (chunk > 0 && B > 0 && (m->variant == 2 || (m->variant == 0 && n_chunks <= max_chunks))) {
-    const size_t need = (SPLIT_CNT_FLOATS + (size_t)m->cus * m->layers * 2 * 256) * sizeof(float);
-    if (m->scratch_bytes < need) {  // first use: sized for a full launch
-      if (m->scratch) (void)hipFree(m->scratch);
-      m->scratch = nullptr;
-      m->scratch_bytes = 0;
-      CET_HIP(hipMalloc(&m->scratch, need));
-      m->scratch_bytes = need;
+  bool split = chunk > 0 && B > 0 && (m->variant >= 2 || (m->variant == 0 && n_chunks <= max_chunks));
+  if (split) {
+    // Under stream capture the launches would be replayed later, outside the pool's bookkeeping:
+    // the batch-tiled kernel needs no buffer (cet_rnn_rollout_static serves captured small batches).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    CET_HIP(hipStreamIsCapturing(stream, &cap));
+    if (cap != hipStreamCaptureStatusNone) {
+      if (m->variant >= 2) return CET_ERR_UNSUPPORTED;
+      split = false;
     }
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-      const int nb = B - b0 < chunk ? B - b0 : chunk;
-      if (!split_fits(m, nb, m->cus)) return CET_ERR_TOO_LARGE;
-      const int rc = rollout_split(m, x + (size_t)b0 * seq_len * m->F, out + (size_t)b0 * pred_len * m->F, nb,
-                                   seq_len, pred_len, m->scratch, stream);
-      if (rc != CET_OK) return rc;
-    }
-    return CET_OK;
   }
-  RArgs a{};
-  a.wstream = m->wstream; a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b;
-  a.dec_w = m->dec_w; a.dec_b = m->dec_b; a.x = x; a.out = out;
-  a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F; a.IP = m->IP;
+  if (split) {
+    SplitPool* pool = nullptr;
+    int slot = -1;
+    if (const int rc = split_claim(m, stream, &pool, &slot)) return rc;
+    int rc = CET_OK;
+    for (int b0 = 0; b0 < B && rc == CET_OK; b0 += chunk) {
+      const int nb = B - b0 < chunk ? B - b0 : chunk;
+      rc = !split_fits(m, nb, m->cus)
+               ? CET_ERR_TOO_LARGE
+               : rollout_split(m, x + (size_t)b0 * seq_len * m->F, out + (size_t)b0 * pred_len * m->F, nb,
+                               seq_len, pred_len, pool->slot[slot].buf, stream);
+    }
+    {  // the slot is free again behind whatever was launched
+      std::lock_guard<std::mutex> lock(pool->mu);
+      const hipError_t e = hipEventRecord(pool->slot[slot].done, stream);
+      if (e != hipSuccess && rc == CET_OK) rc = hip_fail(e);
+    }
+    return rc;
+  }
+  RArgs a = tiled_args(m, x, out, B, seq_len, pred_len);
 #ifdef CET_PROF
   static unsigned long long* prof_dev = nullptr;
   const size_t prof_bytes = (size_t)RP_SLOTS * 4 * RP_WORDS * sizeof(unsigned long long);

@@ -8,6 +8,7 @@ only *hold* parameters: all arithmetic happens in the HIP kernels of csrc/ (reac
 raises.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -206,8 +207,13 @@ class _InformerBase(_DeviceWeights):
         rc = L.cet_informer_create(ctypes.byref(self._cfg), blob.ctypes.data_as(ctypes.c_void_p),
                                    blob.size, ctypes.byref(h))
         _cabi.check(rc, "cet_informer_create")
-        if self._kernel_choice != (-1, -1):
-            _cabi.check(L.cet_informer_select(h, *self._kernel_choice), "cet_informer_select")
+        choice = self._kernel_choice
+        if choice == (-1, -1):  # nothing pinned on the object: the environment may pin (tools, tests)
+            k = os.environ.get("CET_INFORMER_KERNEL", "")
+            p = os.environ.get("CET_INFORMER_PACK", "")
+            choice = ({"o": 1, "w": 2}.get(k[:1], -1 if not k else 0), -1 if not p else int(p[0] != "0"))
+        if choice != (-1, -1):
+            _cabi.check(L.cet_informer_select(h, *choice), "cet_informer_select")
         return h, L.cet_informer_attn_size(h, 1)
 
     _KERNELS = {None: -1, "auto": 0, "one_wave": 1, "workgroup": 2}
@@ -312,16 +318,19 @@ class _RecurrentBase(_DeviceWeights):
                                         self.num_layers, blob.ctypes.data_as(ctypes.c_void_p),
                                         blob.size, ctypes.byref(h))
         _cabi.check(rc, "cet_rnn_create")
-        if self._kernel_choice:
-            _cabi.check(_cabi.lib().cet_rnn_select(h, self._kernel_choice), "cet_rnn_select")
+        choice = self._kernel_choice or {"t": 1, "s": 2}.get(os.environ.get("CET_RNN_KERNEL", "")[:1], 0)
+        if choice:
+            _cabi.check(_cabi.lib().cet_rnn_select(h, choice), "cet_rnn_select")
         return h, None
 
-    _KERNELS = {"auto": 0, "tiled": 1, "split": 2}
+    _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3}
 
     def select_kernel(self, kernel):
         """Pins the rollout kernel (tests, timing): "tiled" (a workgroup takes 32 sequences and all
         hidden units), "split" (small batches: 16 sequences and 16 hidden units per workgroup,
-        hidden states exchanged once per layer and step) or "auto" (by batch size, the default)."""
+        hidden states exchanged once per layer and step), "auto" (by batch size, the default) or
+        "split_giveup" (tests: the hidden-split kernel abandons its exchange at once, so that the
+        stand-by launch of the tiled kernel behind it computes the result)."""
         self._kernel_choice = self._KERNELS[kernel]
         for _v, h, _x in self._handles.values():
             _cabi.check(_cabi.lib().cet_rnn_select(ctypes.c_void_p(h), self._kernel_choice), "cet_rnn_select")

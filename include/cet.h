@@ -152,14 +152,20 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
 /* Pins the kernel of later rollouts of this handle (tests and timing): 0 by batch size, 1 the
  * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
  * kernel for small batches (16 sequences and 16 hidden units per workgroup, hidden states
- * exchanged through a scratch buffer once per layer and step; one launch takes as many sequences
- * as ceil(B / 16) * hidden / 16 workgroups fit the device's CU count, all resident at once, and
- * larger batches go through it in chunks, launch after launch - which choice 0 does for as long
- * as it beats the batch-tiled kernel, a few chunks; when
- * other work on the GPU keeps part of that grid from becoming resident, the exchange gives up
- * after about a second and the predictions of the call are NaN instead of a result).
- * Not to be called while a rollout of the same handle runs on another thread. No counterpart in
- * the reference. */
+ * exchanged through a buffer of the library once per layer and step; one launch takes as many
+ * sequences as ceil(B / 16) * hidden / 16 workgroups fit the device's CU count, larger batches go
+ * through it in chunks, launch after launch - which choice 0 does for as long as it beats the
+ * batch-tiled kernel, a few chunks), 3 the same with an exchange that gives up at its first
+ * unanswered poll (tests: every chunk is then computed by the stand-by launch described next).
+ * Rollouts on the hidden-split kernel may overlap freely, on any streams and handles: each call
+ * claims one of four exchange buffers per GPU (a call that finds all four in flight on other
+ * streams queues its stream behind one of them), and behind every hidden-split launch the
+ * batch-tiled kernel is launched on the same stream on stand-by; it returns at once unless the
+ * exchange gave up (other work kept part of the grid from becoming resident for about a second),
+ * in which case it computes that chunk. Under stream capture choice 0 uses the batch-tiled kernel
+ * and choices 2 / 3 return CET_ERR_UNSUPPORTED (cet_rnn_rollout_static serves captured small
+ * batches). Not to be called while a rollout of the same handle runs on another thread. No
+ * counterpart in the reference. */
 int cet_rnn_select(cet_handle h, int kernel);
 
 /* cet_rnn_rollout for callers that cannot allocate device memory (code under HIP graph capture,
@@ -168,7 +174,8 @@ int cet_rnn_select(cet_handle h, int kernel);
  * cet_rnn_rollout allocates on its first small batch. Calls hipMalloc / hipFree on no path.
  * Limit: ceil(B / 16) * hidden / 16 <= min(256, CU count) (B <= 256 at hidden 256, B <= 512 at
  * hidden 128), else CET_ERR_TOO_LARGE. All calls on one GPU share the array: calls that overlap in
- * time on one GPU (other streams, other handles) race. No counterpart in the reference. */
+ * time on one GPU (other streams, other handles) race (cet_rnn_rollout has no such limit). The
+ * stand-by launch of the batch-tiled kernel follows here too. No counterpart in the reference. */
 int cet_rnn_rollout_static(cet_handle h, const float* x, float* out, int B, int seq_len,
                            int pred_len, void* stream);
 

@@ -45,3 +45,75 @@ def test_two_streams_share_the_handles():
         for a, b in zip(w, g):
             a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
             assert torch.equal(a, b)
+
+
+def _histories(B, seed):
+    noisy, _ = synth.channel_histories(B, seed=seed)
+    return cet.LoadBatch(noisy[:, :25]).cuda()
+
+
+def test_hidden_split_rollouts_of_one_handle_overlap_on_two_streams():
+    """Both streams run hidden-split rollouts of ONE handle at the same time (each call claims an
+    exchange buffer of its own): the bits of the single-stream results, no NaN."""
+    gru = build_rnn("GRU", "split")
+    xs = [_histories(200, 3), _histories(256, 4)]
+    want = [gru.test_data(x, 5, "cuda") for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for _ in range(12):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                got[i].append(gru.test_data(xs[i], 5, "cuda"))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for g in got[i]:
+            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+
+
+def test_more_streams_than_exchange_buffers():
+    """Six streams, three handles (GRU, LSTM, RNN), small and chunked batches, next to the
+    Transformer's workgroup kernel (whose workgroups fill the LDS of their CUs): more rollouts in
+    flight than the four exchange buffers of the GPU. Every result equals its single-stream bits."""
+    models = [build_rnn(n, "split") for n in ("GRU", "LSTM", "RNN")]
+    inf = build_informer("InformerStack", DEFAULT_ARGS, dict(load_npz("informer_ckpt.npz"))).cuda()
+    xi = _histories(8192, 9)
+    xdi = cet.decoder_input(xi, 10, 5)
+    jobs = [(models[k % 3], _histories(B, 10 + k)) for k, B in enumerate((64, 300, 256, 17, 520, 128))]
+    want = [m.test_data(x, 5, "cuda") for m, x in jobs]
+    want_inf = inf(xi, xdi)[0]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in jobs]
+    side = torch.cuda.Stream()
+    got = [[] for _ in jobs]
+    got_inf = []
+    for r in range(6):
+        with torch.cuda.stream(side):
+            got_inf.append(inf(xi, xdi)[0])
+        for i, (m, x) in enumerate(jobs):
+            with torch.cuda.stream(streams[i]):
+                got[i].append(m.test_data(x, 5, "cuda"))
+    torch.cuda.synchronize()
+    for i in range(len(jobs)):
+        for g in got[i]:
+            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+    for g in got_inf:
+        assert torch.equal(g, want_inf)
+
+
+@pytest.mark.parametrize("name", ["GRU", "LSTM", "RNN"])
+def test_abandoned_exchange_is_recomputed_by_the_stand_by_launch(name):
+    """"split_giveup" makes the hidden-split kernel abandon its exchange at the first unanswered
+    poll, as it would after a second of waiting for workgroups that other work keeps from becoming
+    resident: the batch-tiled kernel launched behind it must then deliver the batch-tiled bits, for
+    one launch and for a chunked batch; with a working exchange it must leave the results alone."""
+    m = build_rnn(name, "tiled")
+    for B in (45, 300):
+        x = _histories(B, B)
+        tiled = m.select_kernel("tiled").test_data(x, 7, "cuda")
+        split = m.select_kernel("split").test_data(x, 7, "cuda")
+        rescued = m.select_kernel("split_giveup").test_data(x, 7, "cuda")
+        assert torch.isfinite(rescued).all()
+        assert torch.equal(rescued, tiled)
+        assert not torch.equal(split, tiled)  # other summation order: the stand-by launch stood by
+        assert (split - tiled).abs().max() < 1e-4 * max(1.0, float(tiled.abs().max()))

@@ -21,8 +21,30 @@ def test_static_scratch_rollout_equals_the_allocating_entry_point(name):
     assert L.cet_rnn_create(kind, F, I, H, layers, blob.ctypes.data_as(ctypes.c_void_p), blob.size,
                             ctypes.byref(h)) == 0
     try:
-        assert L.cet_rnn_select(h, 2) == 0  # the existing entry point on the same (hidden-split) kernel
         g = torch.Generator().manual_seed(7)
+        # The very first call on a fresh handle, before cet_rnn_rollout could have prepared anything:
+        # the device's free memory does not move, and the call can be captured into a graph (a
+        # capturing stream refuses every allocation).
+        x0 = (0.7 * torch.randn(33, 25, F, generator=g)).cuda()
+        first = torch.full((33, 5, F), float("nan"), device="cuda")
+        captured = torch.full((33, 5, F), float("nan"), device="cuda")
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        assert L.cet_rnn_rollout_static(h, x0.data_ptr(), first.data_ptr(), 33, 25, 5, None) == 0
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            rc = L.cet_rnn_rollout_static(h, x0.data_ptr(), captured.data_ptr(), 33, 25, 5,
+                                          ctypes.c_void_p(side.cuda_stream))
+            graph.capture_end()
+        assert rc == 0
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(first).all() and torch.equal(captured, first)
+        assert L.cet_rnn_select(h, 2) == 0  # the existing entry point on the same (hidden-split) kernel
         # two calls in a row on the shared array, the second with a smaller input
         for B, seq_len, pred_len in ((61, 25, 5), (19, 12, 3)):
             x = (0.7 * torch.randn(B, seq_len, F, generator=g)).cuda()
