@@ -63,6 +63,7 @@ RNN_FLOP_PER_STEP = {"lstm": 1.614e6, "gru": 1.213e6, "rnn": 0.410e6}
 LMMSE_BYTES = {(16, 4): 688.0, (8, 4): 368.0, (4, 2): 120.0}
 PEAK_FP32_MFMA_TFLOPS = 157.3    # dense fp32 matrix peak of MI355X
 PEAK_HBM_GBS = 8000.0
+CLOCK_SETTLE_MS = 80.0  # the shader clock reaches its steady value some tens of ms into a load
 
 
 def measured_traffic(workload, units, per_unit_key=None):
@@ -97,6 +98,8 @@ def parse(argv=None):
     ap.add_argument("--geometry", default="reference", choices=["reference", "scaled"],
                     help="e2e: 4x2 antennas per subcarrier sample, or 16x4 (eight 4x2 predictor "
                          "sequences per subcarrier)")
+    ap.add_argument("--clock-settle-ms", type=float, default=CLOCK_SETTLE_MS,
+                    help="duration of the untimed clock-settle phase in front of the warm-up steps")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-secondary", action="store_true")
     return ap.parse_args(argv)
@@ -131,13 +134,41 @@ def make_rnn(kind):
     return m.eval(), sd
 
 
-def timed_loop(step, steps, warmup, dist_on, dev):
-    """W untimed steps, then exactly K steps between barrier+synchronize pairs. Returns
-    (wall seconds for the K steps, mean per-step device time in seconds). The device time is one
-    pair of HIP events around the K launches (on the launch stream) divided by K, so it includes
-    the gaps between back-to-back launches; an event pair per step would be the kernel alone but
-    adds two marker packets per launch, which cost 4 % of the step (0.535 against 0.515 ms)."""
+def clock_settle(step, dev, min_ms=CLOCK_SETTLE_MS):
+    """Runs `step` back to back for at least `min_ms` of wall clock and returns the time spent (ms).
+    A GPU that has been idle starts a load at a lower shader clock and needs some tens of
+    milliseconds to settle; without this phase a short `--warmup` measures the ramp (5 warm-up
+    launches of the 0.5 ms Transformer step: 7 % slower than steady state). Not part of the
+    warm-up or step counts of the command line."""
+    t0 = time.perf_counter()
+    if min_ms <= 0:
+        return 0.0
+    step()  # calibration: how many launches make up the phase
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    step()
+    b.record()
+    torch.cuda.synchronize(dev)
+    per_step = max(a.elapsed_time(b), 1e-3)
+    # launched back to back with no host synchronisation in between: gaps in the load keep the
+    # clock from ramping (with a synchronisation every four launches 300 ms were not enough)
+    for _ in range(int(min_ms / per_step) + 1):
+        step()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) * 1e3
+
+
+def timed_loop(step, steps, warmup, dist_on, dev, settle=True):
+    """A clock-settle phase of the same step, W untimed steps, then exactly K steps between
+    barrier+synchronize pairs. Returns (wall seconds for the K steps, mean per-step device time
+    in seconds). The device time is one pair of HIP events around the K launches (on the launch
+    stream) divided by K, so it includes the gaps between back-to-back launches; an event pair per
+    step would be the kernel alone but adds two marker packets per launch, which cost 4 % of the
+    step (0.535 against 0.515 ms)."""
     import torch.distributed as dist
+    if settle:
+        timed_loop.settle_ms = clock_settle(step, dev, timed_loop.min_settle_ms)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -158,6 +189,9 @@ def timed_loop(step, steps, warmup, dist_on, dev):
     return t1 - t0, dev_s
 
 
+timed_loop.min_settle_ms = CLOCK_SETTLE_MS
+
+
 def timed_steady(step, dev, warm_ms=40.0, run_ms=120.0):
     """timed_loop for the secondary lines: step counts from one calibration call, so that every
     line is measured after `warm_ms` of its own load (the shader clock settles within some tens of
@@ -171,7 +205,7 @@ def timed_steady(step, dev, warm_ms=40.0, run_ms=120.0):
     torch.cuda.synchronize(dev)
     t = max(a.elapsed_time(b), 1e-3)
     warm, steps = max(2, int(warm_ms / t + 0.999)), max(5, int(run_ms / t + 0.999))
-    return timed_loop(step, steps, warm, False, dev)[1]
+    return timed_loop(step, steps, warm, False, dev, settle=False)[1]
 
 
 def cpu_baseline_informer(ck, x, xd, budget_s=15.0):
@@ -295,11 +329,34 @@ def free_port():
         return sock.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process's children will see, counted without any HIP or torch.cuda call (the
+    launcher parent must not open the device): the KFD topology nodes that have SIMDs, cut down
+    by the *_VISIBLE_DEVICES lists. 0 when the kernel driver is not loaded (no /sys/class/kfd),
+    None when its topology cannot be read."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip()]))
+    return n
+
+
 def launch_ranks(n, argv):
     """Starts `n` ranks of this script on this node through torch.distributed.run, as a child
-    process (this process has not touched a GPU: no HIP call and no torch.cuda call other than
-    device_count precedes this), waits for them and returns their exit status. Rank 0 of the
-    children prints the JSON line on the shared stdout."""
+    process (this process has not touched a GPU: no HIP call and no torch.cuda call precedes
+    this), waits for them and returns their exit status. Rank 0 of the children prints the JSON
+    line on the shared stdout."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.abspath(__file__)] + list(argv)
@@ -701,12 +758,14 @@ def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
+    timed_loop.min_settle_ms = args.clock_settle_ms
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around this process: become one (nothing here has touched a GPU yet)
-        if args.workload != "selftest" and torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        seen = None if args.workload == "selftest" else visible_gpus()
+        if seen is not None and seen < args.gpus:  # unknown: the ranks fail by themselves
+            raise SystemExit(f"--gpus {args.gpus}: only {seen} GPU(s) visible")
         raise SystemExit(launch_ranks(args.gpus, argv))
 
     import torch.distributed as dist
@@ -808,8 +867,24 @@ def main(argv=None):
         out.update(run_rnn(ctx, args.workload, args.batch or 8192, args.pred_len, args.steps, args.warmup,
                            with_cpu))
 
+    if not cpu_only:
+        out["clock_settle_ms"] = round(getattr(timed_loop, "settle_ms", 0.0), 1)
     if extra:
         out["secondary"] = extra
+    # one compact object as the LAST key: every configuration's [value, unit, roofline fraction]
+    summary = {}
+    if "roofline" in out:
+        summary[out["config"]["workload"].split(",")[0] + f" (headline, B={out['config'].get('batch_per_gpu', '')})"] = [
+            round(out["value"]), out["unit"], round(out["roofline"]["frac"], 4)]
+    for key, line in extra.items():
+        r = line.get("roofline")
+        if not isinstance(r, dict):
+            continue
+        val = line.get("predictions_per_s", line.get("REs_per_s", line.get("equalizer_object_REs_per_s", line.get("value"))))
+        unit = "REs/s" if ("REs_per_s" in line or "equalizer_object_REs_per_s" in line) else "predictions/s"
+        summary[key] = [round(val) if val else None, unit, round(r["frac"], 4)]
+    if summary:
+        out["summary"] = summary
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
