@@ -911,6 +911,119 @@ DEV void decoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
   PROF_MARK(ln, P_ADDLN);
 }
 
+// The two layer forms once more for the large one-wave shapes, which run one wave per SIMD with
+// the register budget that goes with it and have no second wave to cover a load: the weight
+// fragments of every product are requested one product ahead, into two fragment sets used in
+// turn (A, B), so that they travel from L2 during the MFMAs of the product before. Same products,
+// same operand order, same results as encoder_layer / decoder_layer.
+template <int RT, int NHP>
+DEV void encoder_layer_ahead(const float* __restrict__ w, float* smem, int R, const Lane ln, int L,
+                             int activation, float* amap, Act& x) {
+  constexpr int SZ_ATTN = sz_attn<NHP>(), SZ_QKV = sz_qkv<NHP>(), LDQ = ldq<NHP>();
+  const float* nw = w + SZ_ATTN + SZ_FFN;
+  WFrag A, B;
+  NormParams n;
+  Act q, t, y;
+  wave_sync();  // earlier reads of the regions are issued
+  wload<NHP, 4>(A, w, ln);                         // query projection
+  wload<NHP, 4>(B, w + SZ_QKV, ln);                // key projection
+  wmul<RT, NHP, 4>(A, x, q);
+  wload<NHP, 4>(A, w + 2 * SZ_QKV, ln);            // value projection
+  wmul<RT, NHP, 4>(B, x, t);
+  store_rows<RT, NHP, LDQ>(region_k<true, NHP>(smem, R), ln, t, L);
+  wmul<RT, NHP, 4>(A, x, t);
+  store_rows<RT, NHP, LDQ>(region_v<true, NHP>(smem, R), ln, t, L);
+  wave_sync();
+  PROF_MARK(ln, P_QKV);
+  // no fragment set is held across the attention, which needs every register itself
+  attention<RT, RT, true, NHP>(q, nullptr, region_k<true, NHP>(smem, R), region_v<true, NHP>(smem, R), L, L,
+                               false, ln, y, amap);
+  PROF_MARK(ln, P_ATTN);
+  wload<4, NHP>(B, w + 3 * SZ_QKV, ln);            // output projection
+  wload<4, 4>(A, w + SZ_ATTN, ln);                 // conv1
+  load_norm(n, nw, ln);
+  wmul<RT, 4, NHP>(B, y, t);
+  PROF_MARK(ln, P_OPROJ);
+  add_into<RT>(x, t);
+  wload<4, 4>(B, w + SZ_ATTN + SZ_LIN, ln);        // conv2
+  layer_norm<RT>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+  wmul<RT>(A, x, t);
+  activate<RT>(t, activation);
+  load_norm(n, nw + 2 * DM, ln);
+  wmul<RT>(B, t, y);
+  PROF_MARK(ln, P_FFN);
+  add_into<RT>(x, y);
+  layer_norm<RT>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+}
+
+template <int RD, int RM, int NHP>
+DEV void decoder_layer_ahead(const float* __restrict__ w, float* smem, int R, const Lane ln, int Ld,
+                             int Lm, int activation, const Act& mem, Act& x) {
+  constexpr int SZ_ATTN = sz_attn<NHP>(), SZ_QKV = sz_qkv<NHP>(), LDQ = ldq<NHP>();
+  float* Kb = region_k<true, NHP>(smem, R);
+  float* Vb = region_v<true, NHP>(smem, R);
+  const float* wc = w + SZ_ATTN;       // cross attention
+  const float* wf = w + 2 * SZ_ATTN;   // conv1 | conv2
+  const float* nw = wf + SZ_FFN;
+  WFrag A, B;
+  NormParams n;
+  Act q, t, y;
+  // causal self attention
+  wave_sync();
+  wload<NHP, 4>(A, w, ln);
+  wload<NHP, 4>(B, w + SZ_QKV, ln);
+  wmul<RD, NHP, 4>(A, x, q);
+  wload<NHP, 4>(A, w + 2 * SZ_QKV, ln);
+  wmul<RD, NHP, 4>(B, x, t);
+  store_rows<RD, NHP, LDQ>(Kb, ln, t, Ld);
+  wmul<RD, NHP, 4>(A, x, t);
+  store_rows<RD, NHP, LDQ>(Vb, ln, t, Ld);
+  wave_sync();
+  PROF_MARK(ln, P_QKV);
+  attention<RD, RD, true, NHP>(q, nullptr, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
+  PROF_MARK(ln, P_ATTN);
+  wload<4, NHP>(B, w + 3 * SZ_QKV, ln);
+  wload<NHP, 4>(A, wc, ln);                        // cross query projection
+  load_norm(n, nw, ln);
+  wmul<RD, 4, NHP>(B, y, t);
+  PROF_MARK(ln, P_OPROJ);
+  add_into<RD>(x, t);
+  wload<NHP, 4>(B, wc + SZ_QKV, ln);               // cross key projection
+  layer_norm<RD>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+  // cross attention: queries from x, keys / values from the encoder memory
+  wave_sync();
+  wmul<RD, NHP, 4>(A, x, q);
+  wload<NHP, 4>(A, wc + 2 * SZ_QKV, ln);           // cross value projection
+  wmul<RM, NHP, 4>(B, mem, t);
+  store_rows<RM, NHP, LDQ>(Kb, ln, t, Lm);
+  wmul<RM, NHP, 4>(A, mem, t);
+  store_rows<RM, NHP, LDQ>(Vb, ln, t, Lm);
+  wave_sync();
+  PROF_MARK(ln, P_QKV);
+  attention<RD, RM, true, NHP>(q, nullptr, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
+  PROF_MARK(ln, P_ATTN);
+  wload<4, NHP>(B, wc + 3 * SZ_QKV, ln);           // cross output projection
+  wload<4, 4>(A, wf, ln);                          // conv1
+  load_norm(n, nw + 2 * DM, ln);
+  wmul<RD, 4, NHP>(B, y, t);
+  PROF_MARK(ln, P_OPROJ);
+  add_into<RD>(x, t);
+  wload<4, 4>(B, wf + SZ_LIN, ln);                 // conv2
+  layer_norm<RD>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+  wmul<RD>(A, x, t);
+  activate<RD>(t, activation);
+  load_norm(n, nw + 4 * DM, ln);
+  wmul<RD>(B, t, y);
+  PROF_MARK(ln, P_FFN);
+  add_into<RD>(x, y);
+  layer_norm<RD>(x, n, ln);
+  PROF_MARK(ln, P_ADDLN);
+}
+
 // ConvLayer.forward (encoder.py:17-23): Conv1d(64->64, k=3, circular pad 2) -> BatchNorm1d
 // (eval; folded to alpha/beta) -> ELU -> MaxPool1d(3, 2, 1). L rows in, returns rows out.
 // Block: w[3][64][64] (tap-major) | bias | alpha | beta.
@@ -1233,7 +1346,8 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
       amap = cu.attn + (size_t)b * a.n_heads * L * L;
       cu.attn += (size_t)a.B * a.n_heads * L * L;
     }
-    encoder_layer<RT, WG, QR, NHP>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
+    if (!WG && QR) encoder_layer_ahead<RT, NHP>(cu.w, smem, R, ln, L, a.activation, amap, x);
+    else encoder_layer<RT, WG, QR, NHP>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
     if (!ABLATED(a, 8)) cu.w += sz_enc_layer<NHP>();
     tap<RT>(cu.taps, a.B, b, L, ln, x);
   } else if (op.type == OP_DISTIL) {
@@ -1481,7 +1595,8 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
     PROF_MARK(ln, P_EMBED);
   }
   for (int l = 0; l < a.d_layers; ++l) {
-    decoder_layer<RD, RM, WG, QR, NHP>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
+    if (!WG && QR) decoder_layer_ahead<RD, RM, NHP>(cu.w, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
+    else decoder_layer<RD, RM, WG, QR, NHP>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
     if (!ABLATED(a, 8)) cu.w += sz_dec_layer<NHP>();
     tap<RD>(cu.taps, a.B, b, Ld, ln, x);
   }
@@ -2031,8 +2146,27 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     const size_t lds = (size_t)a.wave_lds_floats * sizeof(float);
     if (lds > 64 * 1024) return CET_ERR_UNSUPPORTED;  // cannot happen within supported()'s limits
     const dim3 grid((unsigned)B), block(64);
-    if (large && NHP == 6) hipLaunchKernelGGL((informer_kernel<3, 3, 2, false, 6>), grid, block, lds, stream, a);
-    else if (large) hipLaunchKernelGGL((informer_kernel<3, 3, 2, false, 4>), grid, block, lds, stream, a);
+    // large shapes: decoder and memory row tiles as the model needs them (a 25-row decoder on
+    // three tiles would issue 2.25 times the attention work of two)
+    const int rd = Ld > 32 ? 3 : (Ld > 16 ? 2 : 1);
+#define CET_LAUNCH_LARGE(RD_, RM_, NHP_) \
+  hipLaunchKernelGGL((informer_kernel<3, RD_, RM_, false, NHP_>), grid, block, lds, stream, a)
+#define CET_LAUNCH_LARGE_RM(RD_, NHP_)            \
+  do {                                            \
+    if (m2) CET_LAUNCH_LARGE(RD_, 2, NHP_);       \
+    else CET_LAUNCH_LARGE(RD_, 1, NHP_);          \
+  } while (0)
+#define CET_LAUNCH_LARGE_RD(NHP_)                      \
+  do {                                                 \
+    if (rd == 3) CET_LAUNCH_LARGE_RM(3, NHP_);         \
+    else if (rd == 2) CET_LAUNCH_LARGE_RM(2, NHP_);    \
+    else CET_LAUNCH_LARGE_RM(1, NHP_);                 \
+  } while (0)
+    if (large && NHP == 6) CET_LAUNCH_LARGE_RD(6);
+    else if (large) CET_LAUNCH_LARGE_RD(4);
+#undef CET_LAUNCH_LARGE_RD
+#undef CET_LAUNCH_LARGE_RM
+#undef CET_LAUNCH_LARGE
     else if (!d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 1, 1, false, 4>), grid, block, lds, stream, a);
     else if (!d2 && m2) hipLaunchKernelGGL((informer_kernel<2, 1, 2, false, 4>), grid, block, lds, stream, a);
     else if (d2 && !m2) hipLaunchKernelGGL((informer_kernel<2, 2, 1, false, 4>), grid, block, lds, stream, a);
