@@ -1215,10 +1215,15 @@ int launch_direct(const float* y, const float* H, int no_mode, float no_scalar, 
   return CET_OK;
 }
 
-// LPR: lanes per RE in the tiled kernel, chosen so that a tile's H block is 16 KiB.
+// LPR: lanes per RE (per block in the block-fading kernel; the two kernels use the same value,
+// which fixes the summation order of the Gram matrix and makes their results bit-identical).
+// Two lanes for the four-stream shapes: half the registers per lane and, in the block-fading
+// kernel, half the blocks and so half the result staging area per wave, which is what bounds the
+// resident waves there. Measured (share of 8 TB/s, one / two lanes): block fading 8x4 0.56 / 0.65,
+// 4x4 0.68 / 0.67; per RE 8x4 0.71 / 0.70, 4x4 0.70 / 0.74; two-stream shapes lose with two.
 template <int NR, int NS>
 constexpr int lanes_per_re() {
-  return (NR * NS * 8 >= 512 && NR >= 4) ? 2 : 1;
+  return (NS == 4 && NR >= 4) ? 2 : 1;
 }
 
 template <int NR, int NS>

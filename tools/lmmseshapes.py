@@ -8,8 +8,8 @@ import torch
 import channelestimationtransformer_amd as cet
 
 
-def timed(step, n=30):
-    for _ in range(10):
+def timed(step, n=100):
+    for _ in range(200):  # about 80 ms of load: the shader clock has settled
         step()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
