@@ -497,7 +497,7 @@ struct SArgs {
   const float* dec_b;    // [FP]
   const float* x;        // [B][seq][F]
   float* out;            // [B][pred][F]
-  float* hx;             // exchange: [tile][layer][parity][unit group][256]
+  float* hx;             // exchange: [tile][layer][parity][unit group][sequence][16 units]
   unsigned* cnt;         // arrival counters [tile][layer], zero at launch
   int B, seq_len, pred_len, F, I;
   int spin_limit;        // polls after which a wait gives up
@@ -604,7 +604,13 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
   for (int l = 0; l < NL; ++l) hown[l] = cown[l] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  float* const hx_tile = a.hx + (size_t)tile * NL * 2 * P * 256;
+  // The tile's exchange area [layer][parity][unit group][sequence][16 units] through a buffer
+  // descriptor: 16-byte agent-scope (sc1, write-through / L1-bypassing) stores and loads, a quarter
+  // of the instructions of 4-byte ones and, for the stores, a sixth of their time per byte.
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.hx + (size_t)tile * NL * 2 * P * 256, 0, NL * 2 * P * 256 * 4, 0x00020000);
+  constexpr int AGENT_SCOPE = 16;  // sc1
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   unsigned* const cnt_tile = a.cnt + (size_t)tile * NL * CNT_STRIDE;
   unsigned* const fail = a.cnt + (SPLIT_CNT_FLOATS - 1);  // set by any workgroup whose wait ran out
 
@@ -628,22 +634,26 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
       }
     }
     __syncthreads();
-    const int i = tid >> 6, ll = tid & 63;  // element tid of a slice: unit 4 (ll / 16) + i, sequence ll % 16
-    const int at = (ll & 15) * HS + 4 * (ll >> 4) + i;
-    const float* src = hx_tile + ((size_t)l * 2 + (t & 1)) * P * 256 + tid;
-    const float* src2 = hx_tile + ((size_t)(l2 >= 0 ? l2 : 0) * 2 + (t2 & 1)) * P * 256 + tid;
-    float v[P], v2[P];  // all loads of the round in flight together: one memory round trip
+    // thread tid takes 16 bytes (units 4 u4 .. + 3 of sequence sq) of slices tid / 64 + 4 r
+    const int sq = (tid & 63) >> 2, u4 = tid & 3;
+    const unsigned voff = (unsigned)(tid * 4) * 4u;  // floats (tid / 64) * 256 + sq * 16 + 4 u4 of the layer's state
+    const unsigned so = (unsigned)((l * 2 + (t & 1)) * P * 256) * 4u;
+    const unsigned so2 = (unsigned)(((l2 >= 0 ? l2 : 0) * 2 + (t2 & 1)) * P * 256) * 4u;
+    u32x4 v[P / 4], v2[P / 4];  // all loads of the round in flight together: one memory round trip
 #pragma unroll
-    for (int s = 0; s < P; ++s) v[s] = __hip_atomic_load(src + s * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = 0; r < P / 4; ++r)
+      v[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, voff + (unsigned)(r * 4 * 256 * 4), so, AGENT_SCOPE);
     if (l2 >= 0) {
 #pragma unroll
-      for (int s = 0; s < P; ++s) v2[s] = __hip_atomic_load(src2 + s * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int r = 0; r < P / 4; ++r)
+        v2[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, voff + (unsigned)(r * 4 * 256 * 4), so2, AGENT_SCOPE);
     }
+    const int at = sq * HS + 16 * (tid >> 6) + 4 * u4;
 #pragma unroll
-    for (int s = 0; s < P; ++s) hfull[l][at + 16 * s] = v[s];
+    for (int r = 0; r < P / 4; ++r) st4(&hfull[l][at + 64 * r], __builtin_bit_cast(f32x4, v[r]));
     if (l2 >= 0) {
 #pragma unroll
-      for (int s = 0; s < P; ++s) hfull[l2][at + 16 * s] = v2[s];
+      for (int r = 0; r < P / 4; ++r) st4(&hfull[l2][at + 64 * r], __builtin_bit_cast(f32x4, v2[r]));
     }
     __syncthreads();
   };
@@ -769,10 +779,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
           hn[i] = hv;
         }
         hown[l] = hn;
-        float* dst = hx_tile + (((size_t)l * 2 + (t & 1)) * P + ug) * 256;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)  // element i * 64 + lane: 256 contiguous bytes per store instruction
-          __hip_atomic_store(dst + i * 64 + lane, hn[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // units 4 g .. + 3 of sequence c: one 16-byte store per lane, the slice's 1 KiB in whole lines
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hn), hx_rsrc, (unsigned)(c * 16 + 4 * g) * 4u,
+                                               (unsigned)(((l * 2 + (t & 1)) * P + ug) * 256) * 4u, AGENT_SCOPE);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
           __hip_atomic_fetch_add(cnt_tile + l * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
