@@ -269,7 +269,7 @@ int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float
 
 int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, int P, int C,
                   void* stream) {
-  if (!pred || !truth || !sums || B < 0 || P < 1 || C < 4 || C % 4) return CET_ERR_INVALID_ARG;
+  if (!pred || !truth || !sums || B < 0 || P < 1 || C < 1) return CET_ERR_INVALID_ARG;
   return nmse_sums_launch(pred, truth, sums, B, P, C, static_cast<hipStream_t>(stream));
 }
 

@@ -58,6 +58,31 @@ __global__ __launch_bounds__(256) void nmse_sums_kernel(const float* __restrict_
   }
 }
 
+// The same sums one float per thread: any C, any alignment (the 16-byte form above needs C % 4 == 0
+// and 16-byte aligned arrays). Same accumulation (fp64 per thread, wave, workgroup, one atomic).
+__global__ __launch_bounds__(256) void nmse_sums_kernel_any(const float* __restrict__ pred,
+                                                            const float* __restrict__ truth,
+                                                            double* __restrict__ sums, long B, int P,
+                                                            int C) {
+  const int p = blockIdx.y;
+  const long n = B * C;  // floats of this slot
+  double err = 0.0, pow = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / C;
+    const size_t at = ((size_t)b * P + p) * C + (size_t)(i - b * C);
+    const double t = (double)truth[at], d = t - (double)pred[at];
+    err += d * d;
+    pow += t * t;
+  }
+  __shared__ double red[8];
+  err = block_sum(err, red);
+  pow = block_sum(pow, red + 4);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + p, err);
+    atomicAdd(sums + P + p, pow);
+  }
+}
+
 // x_hat, x_true [N] complex64 (interleaved). out[0] += bit errors of the hard decisions
 // (real > 0, imag > 0), out[1] += 2 N.
 __global__ __launch_bounds__(256) void qpsk_errors_kernel(const float2* __restrict__ x_hat,
@@ -93,10 +118,15 @@ int nmse_sums_launch(const float* pred, const float* truth, double* sums, long B
                      hipStream_t stream) {
   CET_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)P * sizeof(double), stream));
   if (B == 0) return CET_OK;
-  long blocks = (B * (C / 4) + 255) / 256;
+  const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(truth)) & 15) == 0;
+  long blocks = (B * (vec ? C / 4 : C) + 255) / 256;
   if (blocks > 128) blocks = 128;  // x P slots
-  hipLaunchKernelGGL(nmse_sums_kernel, dim3((unsigned)blocks, (unsigned)P), dim3(256), 0, stream, pred,
-                     truth, sums, B, P, C);
+  if (vec)
+    hipLaunchKernelGGL(nmse_sums_kernel, dim3((unsigned)blocks, (unsigned)P), dim3(256), 0, stream, pred,
+                       truth, sums, B, P, C);
+  else
+    hipLaunchKernelGGL(nmse_sums_kernel_any, dim3((unsigned)blocks, (unsigned)P), dim3(256), 0, stream, pred,
+                       truth, sums, B, P, C);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }

@@ -13,8 +13,7 @@ def nmse_partial_sums(pred, truth):
     if torch.is_complex(pred):
         pred, truth = torch.view_as_real(pred), torch.view_as_real(truth)
     B, P = pred.shape[0], pred.shape[1]
-    if pred.is_cuda and pred.dtype == torch.float32 and truth.dtype == torch.float32 and B > 0 \
-            and (pred[0, 0].numel() % 4 == 0):
+    if pred.is_cuda:  # GPU tensors: the HIP kernel, whatever the antenna count (no second arithmetic on the GPU)
         from . import ops  # noqa: F401
         return torch.ops.cet.nmse_sums(pred.reshape(B, P, -1), truth.reshape(B, P, -1))
     d = (truth.double() - pred.double()).reshape(B, P, -1)

@@ -264,7 +264,8 @@ int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float
 
 /* Per prediction slot s: sums[s] = sum (truth - pred)^2, sums[P + s] = sum truth^2 over batch and
  * the C real components (2 per antenna pair); NMSE_s = sums[s] / sums[P + s] is the quantity of
- * HPC/python/Evaluate.py:172-177. pred, truth: device [B,P,C] float32, C % 4 == 0;
+ * HPC/python/Evaluate.py:172-177. pred, truth: device [B,P,C] float32 (any C >= 1; 16-byte loads
+ * when C % 4 == 0 and both arrays are 16-byte aligned, single floats otherwise);
  * sums: device double[2*P], overwritten. Accumulation in fp64. */
 int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, int P, int C,
                   void* stream);

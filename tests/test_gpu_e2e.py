@@ -98,7 +98,8 @@ def test_evaluation_sum_kernels_match_float64():
     """NMSE partial sums and QPSK bit errors from the HIP reductions vs numpy float64."""
     from channelestimationtransformer_amd import metrics
     rng = np.random.default_rng(3)
-    for B, P, C in ((1, 5, 16), (777, 5, 16), (4096, 25, 32)):
+    # C % 4 != 0 (an odd number of antenna pairs) and 1 float: the one-float-per-thread kernel
+    for B, P, C in ((1, 5, 16), (777, 5, 16), (4096, 25, 32), (777, 5, 6), (300, 3, 18), (50, 7, 1)):
         t = rng.standard_normal((B, P, C)).astype(np.float32)
         p = (t + 0.1 * rng.standard_normal((B, P, C))).astype(np.float32)
         got = metrics.nmse_partial_sums(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
@@ -111,6 +112,17 @@ def test_evaluation_sum_kernels_match_float64():
     got = metrics.nmse_partial_sums(torch.from_numpy(pc).cuda(), torch.from_numpy(tc).cuda()).cpu().numpy()
     want = np.stack([(np.abs(tc.astype(np.complex128) - pc) ** 2).sum((0, 2, 3)), (np.abs(tc.astype(np.complex128)) ** 2).sum((0, 2, 3))])
     assert np.allclose(got, want, rtol=1e-12)
+    tc = (rng.standard_normal((41, 4, 3, 1)) + 1j * rng.standard_normal((41, 4, 3, 1))).astype(np.complex64)  # 3 x 1 antennas
+    pc = (tc * 0.9).astype(np.complex64)
+    got = metrics.nmse_partial_sums(torch.from_numpy(pc).cuda(), torch.from_numpy(tc).cuda()).cpu().numpy()
+    want = np.stack([(np.abs(tc.astype(np.complex128) - pc) ** 2).sum((0, 2, 3)), (np.abs(tc.astype(np.complex128)) ** 2).sum((0, 2, 3))])
+    assert np.allclose(got, want, rtol=1e-12)
+    # a view that starts 4 bytes into its storage: the one-float kernel, same sums
+    tt = torch.from_numpy(rng.standard_normal(64 * 5 * 16 + 1).astype(np.float32)).cuda()
+    t1, p1 = tt[1:].view(64, 5, 16), (tt[1:] * 1.05).view(64, 5, 16)
+    assert t1.data_ptr() % 16 != 0
+    got = metrics.nmse_partial_sums(p1, t1)
+    assert torch.allclose(got, metrics.nmse_partial_sums(p1.clone(), t1.clone()), rtol=1e-12)
     for N in (1, 2, 1000, 1001, 1 << 20, (1 << 21) + 7):
         xt = ((2 * rng.integers(0, 2, N) - 1) + 1j * (2 * rng.integers(0, 2, N) - 1)).astype(np.complex64)
         xh = (xt + 1.2 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))).astype(np.complex64)
