@@ -1,7 +1,7 @@
 """Throughput benchmark of the predictor + LMMSE inference path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-                    [--workload informer|lmmse|lstm|gru|rnn|e2e|selftest] [--batch B]
+                    [--workload informer|informer12|lmmse|lstm|gru|rnn|e2e|selftest] [--batch B]
                     [--pred-len P] [--h-share n] [--geometry reference|scaled]
                     [--no-attention-maps]
 
@@ -88,7 +88,8 @@ def parse(argv=None):
     # launches of the 0.5 ms Transformer step measured 4 % slower than 50 or 500)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="informer", choices=["informer", "lmmse", "lstm", "gru", "rnn", "e2e", "selftest"])
+    ap.add_argument("--workload", default="informer",
+                    choices=["informer", "informer12", "lmmse", "lstm", "gru", "rnn", "e2e", "selftest"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (sequences or REs)")
     ap.add_argument("--pred-len", type=int, default=25, help="rollout horizon of the recurrent workloads")
     ap.add_argument("--no-attention-maps", action="store_true",
@@ -529,6 +530,41 @@ def run_e2e(ctx, scaled, S, steps, warmup):
     }
 
 
+def run_informer12(ctx, B, steps, warmup, steady=False):
+    """The shipped 12-head / 35-slot / 25-decoder-row checkpoint (large launch shape of the
+    Transformer kernel, one wave per sequence), output_attention=False, B sequences per GPU."""
+    dev = ctx.dev
+    h12 = np.load(os.path.join(GOLDEN, "informer_h12.npz"))
+    m12 = cet.InformerStack(16, 16, 16, 35, 20, 5, 5, 64, 12, 4, 3, 64, 0.05, "full", "fixed", "gelu",
+                            False, True)
+    m12.load_state_dict(torch_sd({k[len("h12/sd/"):].replace("module.", "", 1): h12[k]
+                                  for k in h12.files if k.startswith("h12/sd/")}))
+    m12 = m12.eval().to(dev)
+    noisy12, _ = synth.channel_histories_device(B, dev, T=40, seed=12 + ctx.rank)
+    x12 = cet.load_batch_device(noisy12[:, :35]).contiguous()
+    xd12 = cet.decoder_input(x12, 20, 5)
+    if steady:
+        wall = dev_s = timed_steady(lambda: m12(x12, xd12), dev)
+        steps = 1
+    else:
+        wall, dev_s = timed_loop(lambda: m12(x12, xd12), steps, warmup, ctx.dist_on, dev)
+        wall = ctx.max_over_ranks(wall)
+    f12 = informer_flop(35, 20, 5, H=12)
+    achieved = f12 * B / dev_s / 1e12
+    return {
+        "metric": "channel predictions/s (Transformer predictor forward, 12-head checkpoint)",
+        "value": B * ctx.n_gpus * steps / wall, "unit": "predictions/s", "ms_per_step": wall / steps * 1e3,
+        "dtype": "f32",
+        "config": {"workload": "InformerStack forward, shipped InformerStack_5x_d_model64_n_heads12_..._seq_len35_"
+                               "label_len20_pred_len5 checkpoint, output_attention=False",
+                   "batch_per_gpu": B, "global_batch": B * ctx.n_gpus, "parallelism": f"dp{ctx.n_gpus}"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "informer_kernel<3,2,1,false,6>", "kernel_ms": dev_s * 1e3,
+                     "flop_per_launch": f12 * B, "flop_per_prediction": f12},
+    }
+
+
 def run_selftest(ctx):
     """No GPU work: every rank forms the NMSE partial sums of its contiguous shard of a seeded
     batch on the CPU, one all-reduce sums them, rank 0 checks the total against the whole batch.
@@ -575,23 +611,12 @@ def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
         "mfma_frac": INFORMER_FLOP * B / d2 / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "roofline": roof("mfma", INFORMER_FLOP * B / d2 / 1e12, d2 * 1e3)}
     # the shipped 12-head / 35-slot / 25-decoder-row checkpoint (large one-wave launch shape)
-    h12 = np.load(os.path.join(GOLDEN, "informer_h12.npz"))
-    m12 = cet.InformerStack(16, 16, 16, 35, 20, 5, 5, 64, 12, 4, 3, 64, 0.05, "full", "fixed", "gelu",
-                            False, True)
-    m12.load_state_dict(torch_sd({k[len("h12/sd/"):].replace("module.", "", 1): h12[k]
-                                  for k in h12.files if k.startswith("h12/sd/")}))
-    m12 = m12.eval().to(dev)
-    noisy12, _ = synth.channel_histories_device(B, dev, T=40, seed=12)
-    x12 = cet.load_batch_device(noisy12[:, :35]).contiguous()
-    xd12 = cet.decoder_input(x12, 20, 5)
-    d12 = timed_steady(lambda: m12(x12, xd12), dev)
-    f12 = informer_flop(35, 20, 5, H=12)
+    r12 = run_informer12(Ctx(dev, 0, 1, False), B, 0, 0, steady=True)
     extra["informer_12_heads_35_slots"] = {
-        "predictions_per_s": B / d12, "kernel_ms": d12 * 1e3, "flop_per_prediction": f12,
-        "roofline": roof("mfma", f12 * B / d12 / 1e12, d12 * 1e3),
+        "predictions_per_s": r12["value"], "kernel_ms": r12["roofline"]["kernel_ms"],
+        "flop_per_prediction": r12["roofline"]["flop_per_prediction"], "roofline": r12["roofline"],
         "note": "shipped InformerStack_5x_d_model64_n_heads12_..._seq_len35_label_len20 checkpoint, "
                 f"B={B}, output_attention=False"}
-    del m12, x12, xd12, noisy12
     # the reference's own GPU path on this card: the model in stock PyTorch-ROCm eager
     # calls (oracle/torch_ref.py on device tensors), same weights, same batch
     from oracle import torch_ref as _tr
@@ -856,6 +881,8 @@ def main(argv=None):
                 "c_checker": cpu_baseline_informer(ck, x.cpu().numpy(), xd.cpu().numpy(), budget_s=5.0)}
         if rank == 0 and n_gpus == 1 and not args.skip_secondary:
             extra = secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s)
+    elif args.workload == "informer12":
+        out.update(run_informer12(ctx, args.batch or 4096, args.steps, args.warmup))
     elif args.workload == "e2e":
         out.update(run_e2e(ctx, args.geometry == "scaled", args.batch or 3276 * 8, args.steps, args.warmup))
     elif args.workload == "lmmse":

@@ -1,4 +1,4 @@
-"""Turns one tools/profile_r2.sh output directory into the files kept under profiles/.
+"""Turns one tools/profile_r2.sh / profile_r3.sh output directory into the files kept under profiles/.
 
 Usage: python tools/summarize_counters.py gpurun_out/prof_<tag> <tag> [output directory]
 Writes
@@ -23,6 +23,8 @@ INFORMER_MAPS = 8 * sum(L * L for L in (25, 14, 8, 5, 5, 4, 3)) * 4
 WORKLOADS = {
     "informer": ("informer_kernel<2, 1, 1, true, 4>", "default (B=4096, output_attention=True)", 4096, INFORMER_IO + INFORMER_MAPS),
     "informer_nomaps": ("informer_kernel<2, 1, 1, true, 4>", "--no-attention-maps (B=4096)", 4096, INFORMER_IO),
+    "informer12": ("informer_kernel<3, 2, 1, false, 6>", "--workload informer12 (B=4096, 12 heads, 35 slots)", 4096,
+                   (35 + 25 + 5) * 16 * 4),
     "lstm": ("rnn_rollout_kernel", "--workload lstm --pred-len 5 (B=8192)", 8192, 25 * 16 * 4 + 5 * 16 * 4),
     "gru": ("rnn_rollout_kernel", "--workload gru --pred-len 5 (B=8192)", 8192, 25 * 16 * 4 + 5 * 16 * 4),
     "rnn": ("rnn_rollout_kernel", "--workload rnn --pred-len 5 (B=8192)", 8192, 25 * 16 * 4 + 5 * 16 * 4),
@@ -84,7 +86,7 @@ def main():
 
     # ---- SQ counters --------------------------------------------------------------------------------
     util = {"_how": (
-        "rocprofv3 --pmc, three passes per workload (tools/profile_r2.sh), bench.py --skip-secondary "
+        "rocprofv3 --pmc, three passes per workload (tools/profile_r3.sh; round 2: profile_r2.sh), bench.py --skip-secondary "
         "--skip-cpu-baseline; values are means per kernel launch over the timed launches. "
         "SQ_*_CYCLES of waves (WAVE_CYCLES, WAIT_*, ACTIVE_INST_*) count quad-cycles summed over waves; "
         "SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; SQ_BUSY_CYCLES is summed over the "
@@ -146,7 +148,7 @@ def main():
                       "fetch_bytes_corrected": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
                       "config": "bench.py " + args, "algorithmic_bytes_per_launch": alg * units, "units": units}
     traffic["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
-                       "(tools/profile_r2.sh); bytes = FETCH_SIZE*1024*2 (gfx950 counts wide 128-B "
+                       "(tools/profile_r3.sh; round 2: profile_r2.sh); bytes = FETCH_SIZE*1024*2 (gfx950 counts wide 128-B "
                        "reads as 64 B) + WRITE_SIZE*1024; mean over the timed launches")
     if len(traffic) > 1:
         with open(os.path.join(out_dir, f"{tag}_hbm_traffic.json"), "w") as f:
