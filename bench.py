@@ -60,7 +60,7 @@ def informer_flop(seq, label, pred, D=64, H=8, e_layers=4, d_layers=3, F=64, cin
                      + 4 * Ld * D * F)
     return f + 2 * Ld * D * cout
 RNN_FLOP_PER_STEP = {"lstm": 1.614e6, "gru": 1.213e6, "rnn": 0.410e6}
-LMMSE_BYTES = {(16, 4): 688.0, (8, 4): 368.0, (4, 2): 120.0}
+LMMSE_BYTES = {(16, 4): 688.0, (8, 4): 368.0, (4, 4): 208.0, (4, 2): 120.0}
 PEAK_FP32_MFMA_TFLOPS = 157.3    # dense fp32 matrix peak of MI355X
 PEAK_HBM_GBS = 8000.0
 CLOCK_SETTLE_MS = 80.0  # the shader clock reaches its steady value some tens of ms into a load
@@ -688,6 +688,17 @@ def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
                                      "hbm_GBps": bpr * Nv / dv / 1e9,
                                      "hbm_frac": bpr * Nv / dv / 1e9 / PEAK_HBM_GBS,
                                      "roofline": roof("hbm", bpr * Nv / dv / 1e9, dv * 1e3)}
+        del yv, Hv
+    # block fading (one matrix per 14 REs) on the other four-stream shapes
+    for (nr, ns) in ((8, 4), (4, 4)):
+        Nv = 1 << 24
+        yv, Hv, _xs = lmmse_inputs(Nv, nr, ns, 0.1, dev, 0, 14)
+        dv = timed_steady(lambda: cet.lmmse(yv, Hv, 0.1, h_share=14), dev)
+        bpr = LMMSE_BYTES[(nr, ns)] - nr * ns * 8 * (1.0 - 1.0 / 14)
+        extra[f"lmmse_{nr}x{ns}_block_fading_14"] = {
+            "REs_per_s": Nv / dv, "kernel_ms": dv * 1e3, "N": Nv, "bytes_per_RE": bpr,
+            "hbm_GBps": bpr * Nv / dv / 1e9, "hbm_frac": bpr * Nv / dv / 1e9 / PEAK_HBM_GBS,
+            "roofline": roof("hbm", bpr * Nv / dv / 1e9, dv * 1e3, kernel=f"lmmse_block<{nr},{ns},2>")}
         del yv, Hv
     # the reference's receive chain on its own grid (EndtoEndtest.py:50-59, 130-133, 184-191):
     # LS estimate with nearest-neighbour interpolation -> LMMSEEqualizer object, 4 rx x 2 streams
