@@ -877,9 +877,11 @@ struct RnnModel {
 // Exchange buffers of the hidden-split kernel: SPLIT_SLOTS per GPU, shared by all handles on it,
 // allocated by the first rollout that needs one and kept until the process ends. A rollout claims
 // a slot for its launches and leaves an event behind them: the next claim takes the slot its own
-// stream used last (stream order protects it), else one whose event has completed, else makes its
-// stream wait for the oldest slot's event. Rollouts of any handles on any streams may therefore
-// overlap; at most SPLIT_SLOTS hidden-split grids are in flight per GPU.
+// stream used last, else one whose event has completed, else makes its stream wait for the oldest
+// slot's event. The pool's mutex is held from the claim until that event is recorded, so a second
+// host thread never sees a claimed slot with the event of its previous use. Rollouts of any
+// handles on any streams may therefore overlap; at most SPLIT_SLOTS hidden-split grids are in
+// flight per GPU.
 constexpr int SPLIT_SLOTS = 4;
 constexpr int SPLIT_MAX_DEVICES = 64;
 struct SplitSlot {
@@ -1153,12 +1155,10 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
   return lf(t, stream);
 }
 
-// Claims an exchange buffer of this device's pool for launches on `stream` (see SplitPool).
-static int split_claim(const RnnModel* m, hipStream_t stream, SplitPool** pool_out, int* slot_out) {
-  if (m->device < 0 || m->device >= SPLIT_MAX_DEVICES) return CET_ERR_UNSUPPORTED;
-  SplitPool& pool = g_split_pool[m->device];
+// Claims an exchange buffer of this device's pool for launches on `stream` (see SplitPool). The
+// caller holds pool.mu and keeps it until it has recorded the slot's event behind its launches.
+static int split_claim(const RnnModel* m, SplitPool& pool, hipStream_t stream, int* slot_out) {
   const size_t need = (SPLIT_CNT_FLOATS + (size_t)m->cus * SPLIT_MAX_LAYERS * 2 * 256) * sizeof(float);
-  std::lock_guard<std::mutex> lock(pool.mu);
   if (pool.slot_bytes < need) {  // first use on this device (the CU count of a device is fixed)
     for (int i = 0; i < SPLIT_SLOTS; ++i) {
       SplitSlot& sl = pool.slot[i];
@@ -1168,23 +1168,23 @@ static int split_claim(const RnnModel* m, hipStream_t stream, SplitPool** pool_o
     pool.slot_bytes = need;
   }
   int pick = -1;
-  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i)
+  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i)  // the slot this stream used last
     if (pool.slot[i].used && pool.slot[i].last == stream) pick = i;
-  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i)
+  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i)  // one never used
     if (!pool.slot[i].used) pick = i;
-  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i) {
+  for (int i = 0; i < SPLIT_SLOTS && pick < 0; ++i) {  // one whose launches have finished
     const hipError_t q = hipEventQuery(pool.slot[i].done);
     if (q == hipSuccess) pick = i;
     else if (q != hipErrorNotReady) return hip_fail(q);
   }
-  if (pick < 0) {  // all in flight on other streams: queue behind the one whose turn it is
-    pick = (int)(pool.next++ % SPLIT_SLOTS);
-    CET_HIP(hipStreamWaitEvent(stream, pool.slot[pick].done, 0));
-  }
-  // Owned by `stream` from here on; the event is recorded by split_release behind the launches.
+  // all in flight on other streams: queue behind the one whose turn it is
+  if (pick < 0) pick = (int)(pool.next++ % SPLIT_SLOTS);
+  // Behind the slot's previous launches in every case: free when they ran on this stream or have
+  // finished, and it covers a new stream that was given the handle value of a destroyed one whose
+  // work is still running.
+  if (pool.slot[pick].used) CET_HIP(hipStreamWaitEvent(stream, pool.slot[pick].done, 0));
   pool.slot[pick].used = true;
   pool.slot[pick].last = stream;
-  *pool_out = &pool;
   *slot_out = pick;
   return CET_OK;
 }
@@ -1226,22 +1226,22 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
     }
   }
   if (split) {
-    SplitPool* pool = nullptr;
+    if (m->device < 0 || m->device >= SPLIT_MAX_DEVICES) return CET_ERR_UNSUPPORTED;
+    SplitPool& pool = g_split_pool[m->device];
+    std::lock_guard<std::mutex> lock(pool.mu);  // claim, launches and event as one step (see SplitPool)
     int slot = -1;
-    if (const int rc = split_claim(m, stream, &pool, &slot)) return rc;
+    if (const int rc = split_claim(m, pool, stream, &slot)) return rc;
     int rc = CET_OK;
     for (int b0 = 0; b0 < B && rc == CET_OK; b0 += chunk) {
       const int nb = B - b0 < chunk ? B - b0 : chunk;
       rc = !split_fits(m, nb, m->cus)
                ? CET_ERR_TOO_LARGE
                : rollout_split(m, x + (size_t)b0 * seq_len * m->F, out + (size_t)b0 * pred_len * m->F, nb,
-                               seq_len, pred_len, pool->slot[slot].buf, stream);
+                               seq_len, pred_len, pool.slot[slot].buf, stream);
     }
-    {  // the slot is free again behind whatever was launched
-      std::lock_guard<std::mutex> lock(pool->mu);
-      const hipError_t e = hipEventRecord(pool->slot[slot].done, stream);
-      if (e != hipSuccess && rc == CET_OK) rc = hip_fail(e);
-    }
+    // the slot is free again behind whatever was launched
+    const hipError_t e = hipEventRecord(pool.slot[slot].done, stream);
+    if (e != hipSuccess && rc == CET_OK) rc = hip_fail(e);
     return rc;
   }
   RArgs a = tiled_args(m, x, out, B, seq_len, pred_len);

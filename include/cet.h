@@ -157,8 +157,8 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * through it in chunks, launch after launch - which choice 0 does for as long as it beats the
  * batch-tiled kernel, a few chunks), 3 the same with an exchange that gives up at its first
  * unanswered poll (tests: every chunk is then computed by the stand-by launch described next).
- * Rollouts on the hidden-split kernel may overlap freely, on any streams and handles: each call
- * claims one of four exchange buffers per GPU (a call that finds all four in flight on other
+ * Rollouts on the hidden-split kernel may overlap freely, on any streams and handles and from any
+ * host threads: each call claims one of four exchange buffers per GPU (a call that finds all four in flight on other
  * streams queues its stream behind one of them), and behind every hidden-split launch the
  * batch-tiled kernel is launched on the same stream on stand-by; it returns at once unless the
  * exchange gave up (other work kept part of the grid from becoming resident for about a second),

@@ -101,6 +101,45 @@ def test_more_streams_than_exchange_buffers():
         assert torch.equal(g, want_inf)
 
 
+def test_host_threads_claim_exchange_buffers_concurrently():
+    """Six host threads, each on a stream of its own, call hidden-split rollouts of two handles at
+    the same time (the foreign calls run without the interpreter lock): a buffer claimed by one
+    thread must not be handed to another before the first has left its event behind its launches."""
+    import threading
+    models = [build_rnn(n, "split") for n in ("GRU", "RNN")]
+    jobs = [(models[k % 2], _histories(B, 30 + k)) for k, B in enumerate((256, 64, 130, 256, 31, 200))]
+    want = [m.test_data(x, 5, "cuda") for m, x in jobs]
+    torch.cuda.synchronize()
+    got = [[] for _ in jobs]
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def run(i):
+        try:
+            torch.cuda.set_device(0)
+            m, x = jobs[i]
+            s = torch.cuda.Stream()
+            start.wait()
+            with torch.cuda.stream(s):
+                for _ in range(25):
+                    got[i].append(m.test_data(x, 5, "cuda"))
+            s.synchronize()
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(len(jobs)):
+        assert len(got[i]) == 25
+        for g in got[i]:
+            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+
+
 @pytest.mark.parametrize("name", ["GRU", "LSTM", "RNN"])
 def test_abandoned_exchange_is_recomputed_by_the_stand_by_launch(name):
     """"split_giveup" makes the hidden-split kernel abandon its exchange at the first unanswered
