@@ -43,6 +43,13 @@ static int check_device(const cet_handle_s* h) {
   return dev == h->device ? CET_OK : CET_ERR_INVALID_ARG;
 }
 
+// Arrays of interleaved complex64 are read and written as (re, im) pairs.
+static bool pairs_aligned(std::initializer_list<const void*> ptrs) {
+  for (const void* p : ptrs)
+    if (reinterpret_cast<uintptr_t>(p) & 7) return false;
+  return true;
+}
+
 }  // namespace cet
 
 using namespace cet;
@@ -252,6 +259,7 @@ int cet_lmmse_grid(const float* y, const float* h_hat, const float* err_var, int
   if (!y || !h_hat || !data_sym || !eff_sc || !x_hat || !no_eff) return CET_ERR_INVALID_ARG;
   if (no_mode != 0 && !no_dev) return CET_ERR_INVALID_ARG;
   if (no_mode == 0 && !(no_scalar > 0.f) && !err_var) return CET_ERR_INVALID_ARG;
+  if (!pairs_aligned({y, h_hat, x_hat})) return CET_ERR_INVALID_ARG;
   if (Ns > Nr) return CET_ERR_UNSUPPORTED;
   return lmmse_grid_launch(y, h_hat, err_var, no_mode, no_scalar, no_dev, data_sym, eff_sc, x_hat,
                            no_eff, B, Nr, Ns, n_sym, fft, n_sc, n_ds,
@@ -263,18 +271,21 @@ int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float
   if (planes < 0 || plane < 1 || T < 1 || !(no >= 0.f)) return CET_ERR_INVALID_ARG;
   if (planes == 0) return CET_OK;
   if (!y || !src || !pinv || !pabs2inv || !h_hat || !err_var) return CET_ERR_INVALID_ARG;
+  if (!pairs_aligned({y, pinv, h_hat})) return CET_ERR_INVALID_ARG;
   return ls_nn_launch(y, src, pinv, pabs2inv, no, h_hat, err_var, planes, plane, T,
                       static_cast<hipStream_t>(stream));
 }
 
 int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, int P, int C,
                   void* stream) {
-  if (!pred || !truth || !sums || B < 0 || P < 1 || C < 1) return CET_ERR_INVALID_ARG;
+  if (!pred || !truth || !sums || B < 0 || P < 1 || C < 1 || !pairs_aligned({sums}))
+    return CET_ERR_INVALID_ARG;
   return nmse_sums_launch(pred, truth, sums, B, P, C, static_cast<hipStream_t>(stream));
 }
 
 int cet_qpsk_bit_errors(const float* x_hat, const float* x_true, double* out, long N, void* stream) {
-  if (!x_hat || !x_true || !out || N < 0) return CET_ERR_INVALID_ARG;
+  if (!x_hat || !x_true || !out || N < 0 || !pairs_aligned({x_hat, x_true, out}))
+    return CET_ERR_INVALID_ARG;
   return qpsk_errors_launch(x_hat, x_true, out, N, static_cast<hipStream_t>(stream));
 }
 

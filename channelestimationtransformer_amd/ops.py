@@ -159,6 +159,8 @@ def qpsk_bit_errors(x_hat: torch.Tensor, x_true: torch.Tensor) -> torch.Tensor:
     dev = _dev_check(x_hat, x_true)
     x_hat = x_hat.contiguous().float()
     x_true = x_true.contiguous().float()
+    x_hat = x_hat.clone() if x_hat.data_ptr() % 8 else x_hat  # (re, im) pairs are read as one piece
+    x_true = x_true.clone() if x_true.data_ptr() % 8 else x_true
     N = x_hat.numel() // 2
     out = torch.empty((2,), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):

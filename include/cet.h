@@ -193,9 +193,10 @@ enum {
  *   G = (H^H S^-1 H + I)^-1 H^H S^-1,  x_hat = diag(GH)^-1 G y,  no_eff = Re(1/diag(GH) - 1)
  * with S diagonal. Device pointers, interleaved (re,im) float32:
  *   y [N,Nr,2], H [N,Nr,Ns,2]  ->  x_hat [N,Ns,2], no_eff [N,Ns].
- * Supported (Nr,Ns): Nr in {2,4,8,16}, Ns in {1,2,4}, Ns <= Nr. Every device pointer of the
- * LMMSE entry points must be 16-byte aligned (CET_ERR_INVALID_ARG otherwise); the kernels write
- * exactly the N * Ns elements of each output and nothing behind them. */
+ * Supported (Nr,Ns): Nr in {2,4,8,16}, Ns in {1,2,4}, Ns <= Nr. Every device pointer of
+ * cet_lmmse, cet_lmmse_direct, cet_lmmse_llr, cet_lmmse_block and cet_lmmse_block_llr must be
+ * 16-byte aligned (CET_ERR_INVALID_ARG otherwise; the kernels move 16-byte pieces); the kernels
+ * write exactly the N * Ns elements of each output and nothing behind them. */
 int cet_lmmse(const float* y, const float* H, int no_mode, float no_scalar, const float* no_dev,
               float* x_hat, float* no_eff, long N, int Nr, int Ns, void* stream);
 
@@ -240,7 +241,8 @@ int cet_lmmse_block_llr(const float* y, const float* H, int no_mode, float no_sc
  *   data_sym [n_ds] int32 OFDM symbols that carry data, eff_sc [n_sc] int32 subcarrier index in
  *            the fft grid of every effective subcarrier (device arrays)
  *   x_hat    [B, Ns, n_ds * n_sc] complex64, no_eff the same in float32 (OFDM symbol first, then
- *            subcarrier: pilot symbols, guard and DC carriers removed). */
+ *            subcarrier: pilot symbols, guard and DC carriers removed).
+ * The complex arrays must be 8-byte aligned (CET_ERR_INVALID_ARG otherwise). */
 int cet_lmmse_grid(const float* y, const float* h_hat, const float* err_var, int no_mode,
                    float no_scalar, const float* no_dev, const int32_t* data_sym,
                    const int32_t* eff_sc, float* x_hat, float* no_eff, int B, int Nr, int Ns,
@@ -256,7 +258,8 @@ int cet_lmmse_grid(const float* y, const float* h_hat, const float* err_var, int
  *               [symbols * fft_size] plane of y,
  *   pinv[t]     1 / pilot (complex, interleaved),   pabs2inv[t] = 1 / |pilot|^2.
  * y: device [planes, plane] complex64 (planes = batch * receive antennas);
- * h_hat: device [planes, T] complex64, err_var: device [planes, T] float32 = no / |pilot|^2. */
+ * h_hat: device [planes, T] complex64, err_var: device [planes, T] float32 = no / |pilot|^2.
+ * The complex arrays must be 8-byte aligned (CET_ERR_INVALID_ARG otherwise). */
 int cet_ls_nn(const float* y, const int32_t* src, const float* pinv, const float* pabs2inv,
               float no, float* h_hat, float* err_var, long planes, int plane, int T, void* stream);
 
@@ -272,7 +275,8 @@ int cet_nmse_sums(const float* pred, const float* truth, double* sums, long B, i
 
 /* Hard-decision QPSK (bit = sign of the real / imaginary part) of x_hat against x_true, both
  * device complex64 [N] interleaved: out[0] = bit errors, out[1] = bits compared (2 N); the count
- * behind the BER of LocalSimulations/EndtoEndtest.py:196-200. out: device double[2], overwritten. */
+ * behind the BER of LocalSimulations/EndtoEndtest.py:196-200. out: device double[2], overwritten.
+ * All three arrays 8-byte aligned (CET_ERR_INVALID_ARG otherwise). */
 int cet_qpsk_bit_errors(const float* x_hat, const float* x_true, double* out, long N, void* stream);
 
 #ifdef __cplusplus

@@ -89,6 +89,12 @@ def test_misaligned_pointers_are_refused():
         rc = L.cet_lmmse(_ptr(args[0]), _ptr(args[1]), 0, ctypes.c_float(0.1), None, _ptr(args[2]),
                          _ptr(args[3]), N, Nr, Ns, stream)
         assert rc == 1  # CET_ERR_INVALID_ARG
+    # complex arrays of the other entry points: 8 bytes
+    xc = torch.randn(2 * N + 2, device="cuda")
+    out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    assert L.cet_qpsk_bit_errors(_ptr(xc), _ptr(xc), _ptr(out), N, stream) == 0
+    assert L.cet_qpsk_bit_errors(_ptr(xc[1:]), _ptr(xc), _ptr(out), N, stream) == 1
+    assert L.cet_qpsk_bit_errors(_ptr(xc), _ptr(xc[1:]), _ptr(out), N, stream) == 1
     # the torch-level op copies a misaligned slice instead of failing
     yc = torch.view_as_complex(torch.randn(N + 1, 2, 2, device="cuda"))[1:]  # 16 B rows: stays aligned
     assert yc.data_ptr() % 16 == 0
