@@ -17,12 +17,18 @@
 //     registers keeps D loads in flight at all times: a slot is refilled right after its
 //     MFMAs were issued, across unit tiles, layers, barriers and time steps (the stream wraps),
 //     so L2 latency is paid once per launch instead of once per matrix.
-//   * Biases and the encoder Linear live in LDS for the whole rollout.
+//   * The encoder Linear is folded into the first layer's input weights at create time
+//     (W_ih0 (We x + be) = (W_ih0 We) x + W_ih0 be, nothing non-linear sits between the two;
+//     products and sums in double, rounded once): the first layer takes the step's features
+//     straight from registers, and a time step has no encoder stage and no barrier for it.
+//   * Biases live in LDS for the whole rollout, b_ih + b_hh summed at create time where the cell
+//     adds them anyway (every gate but the GRU's n).
 //   * The decoder Linear consumes the wave's fresh h straight from the accumulator registers
-//     (k = own units), the four partial sums meet in LDS; the encoder Linear of the next step
-//     consumes that result from registers again. In the closed-loop phase nothing but the
-//     predictions ever goes to HBM.
+//     (k = own units), the four partial sums meet in LDS; the next step consumes that result
+//     from registers again. In the closed-loop phase nothing but the predictions ever goes to
+//     HBM.
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -79,14 +85,14 @@ template <> struct Cell<CET_RNN_LSTM> { static constexpr int G = 4, NACC = 4; };
 
 struct RArgs {
   const float* wstream;  // packed gate weights, [wave][layer][unit tile][x|h][k-block][gate][64][4]
-  const float* bias;     // [layer][2][G*H]   (b_ih, b_hh)
-  const float* enc_w;    // [FP][FP] zero padded (row = encoder output unit)
-  const float* enc_b;    // [FP]
+  // [layer][2][G*H]: b_ih + b_hh | unused, but for the GRU's n gate b_in | b_hn; the first layer's
+  // b_ih includes the folded encoder bias
+  const float* bias;
   const float* dec_w;    // [FP][H] zero padded (row = feature)
   const float* dec_b;    // [FP]
   const float* x;        // [B][seq][F]
   float* out;            // [B][pred][F]
-  int B, seq_len, pred_len, F, IP;  // IP: encoder width padded to 16
+  int B, seq_len, pred_len, F;
   // Conditional launch: when set, the workgroups return at once unless this word is non-zero (the
   // failure flag of the hidden-split rollout launched just before on the same stream).
   const unsigned* only_if;
@@ -173,14 +179,11 @@ DEV void segment(f32x16 (&acc)[Cell<KIND>::NACC], WRing<Cell<KIND>::G, D>& r, co
 
 // The layer-0 input segment: D k-blocks in the stream (so that every segment is a multiple of
 // the ring depth) of which the first nvalid <= 4 carry weights; the rest is fetched and dropped.
-// The activation row holds FP = 32 values, so reading 4 k-blocks of it is always in bounds.
+// b: the step's features as they sit in registers (k-block q <-> features 8 q + 4 hh .. + 3).
 template <int KIND, int D>
 DEV void segment_input(f32x16 (&acc)[Cell<KIND>::NACC], WRing<Cell<KIND>::G, D>& r,
-                       const float* act, const int nvalid) {
+                       const f32x4 (&b)[4], const int nvalid) {
   constexpr int NB = D < 4 ? D : 4;
-  f32x4 b[NB];
-#pragma unroll
-  for (int d = 0; d < NB; ++d) b[d] = ld4(act + 8 * d);
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     if (d < NB) {
@@ -200,12 +203,9 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
   constexpr bool LSTM = KIND == CET_RNN_LSTM;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xbuf = smem;                       // [BT][PSTR]  encoder output (layer-0 input)
-  float* part = xbuf + BT * PSTR;           // [4][BT][PSTR] decoder partial sums
+  float* part = smem;                       // [4][BT][PSTR] decoder partial sums
   float* hbuf = part + 4 * BT * PSTR;       // [NL][BT][HS]
-  float* lbias = hbuf + NL * BT * HS;       // [NL][2][G*H]  (b_ih, b_hh)
-  float* lencw = lbias + NL * 2 * G * H;    // [FP][PSTR]    encoder weight rows
-  float* lencb = lencw + FP * PSTR;         // [FP]
+  float* lbias = hbuf + NL * BT * HS;       // [NL][2][G*H]  (see RArgs::bias)
   constexpr int D = ring_depth(KIND);
   static_assert((H / 8) % D == 0, "segment lengths must be multiples of the ring depth");
 
@@ -231,12 +231,9 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
 #pragma unroll
   for (int d = 0; d < D; ++d) ring_refill(ring, d);
 
-  for (int i = tid; i < (BT * PSTR * 5 + NL * BT * HS) / 4; i += 256)
+  for (int i = tid; i < (BT * PSTR * 4 + NL * BT * HS) / 4; i += 256)
     st4(smem + 4 * i, f32x4{0, 0, 0, 0});
   for (int i = tid; i < NL * 2 * G * H / 4; i += 256) st4(lbias + 4 * i, ld4(a.bias + 4 * i));
-  for (int i = tid; i < FP * FP / 4; i += 256)
-    st4(lencw + (i / (FP / 4)) * PSTR + 4 * (i % (FP / 4)), ld4(a.enc_w + 4 * i));
-  if (tid < FP / 4) st4(lencb + 4 * tid, ld4(a.enc_b + 4 * tid));
 
   f32x16 cst[LSTM ? NL : 1][LSTM ? UT : 1];  // LSTM cell state of this wave's units
 #pragma unroll
@@ -270,31 +267,11 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
     // registers. Making the base pointers opaque per iteration keeps them where they are used.
     const float *dec_w = a.dec_w, *dec_b = a.dec_b;
     asm volatile("" : "+s"(dec_w), "+s"(dec_b));
-    // ---- encoder Linear: xe^T = We * x^T + be, from registers; wave 0 publishes it ----
+    // ---- the next teacher-forced input, requested a step ahead ----
     f32x4 xnext[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) xnext[q] = xin[q];
-    if (idx + 1 < a.seq_len) load_x(idx + 1, xnext);  // prefetch the next teacher-forced input
-    if (wave == 0) {
-      f32x16 e;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = ld4(lencb + 8 * q + 4 * hh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[4 * q + i] = bv[i];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 wv = ld4(lencw + j * PSTR + 8 * q + 4 * hh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e = mfma32(wv[i], xin[q][i], e);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        st4(xbuf + j * PSTR + 8 * q + 4 * hh,
-            f32x4{e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]});
-    }
-    __syncthreads();
+    if (idx + 1 < a.seq_len) load_x(idx + 1, xnext);
     RP_MARK(0)
 
     const bool decode = idx >= a.seq_len - 1;  // decoder output needed from here on
@@ -305,8 +282,7 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
     // ---- the layers ---------------------------------------------------------------------
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      const float* in_buf = l == 0 ? xbuf : hbuf + (l - 1) * BT * HS;
-      const int in_stride = l == 0 ? PSTR : HS;
+      const float* in_buf = hbuf + (l > 0 ? l - 1 : 0) * BT * HS;  // the layer below (l > 0)
       float* hl = hbuf + l * BT * HS;
       const float* bi = lbias + l * 2 * G * H;
       const float* bh = bi + G * H;
@@ -321,23 +297,21 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
           const int off = u0 + 8 * q + 4 * hh;
 #pragma unroll
           for (int gt = 0; gt < G; ++gt) {
-            const f32x4 v1 = ld4(bi + gt * H + off), v2 = ld4(bh + gt * H + off);
+            const f32x4 v1 = ld4(bi + gt * H + off);  // b_ih + b_hh, or b_in
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (KIND == CET_RNN_GRU && gt == 2) {
-                acc[2][4 * q + i] = v1[i];  // n gate keeps W_in x + b_in ...
-                acc[3][4 * q + i] = v2[i];  // ... apart from W_hn h + b_hn
-              } else {
-                acc[gt][4 * q + i] = v1[i] + v2[i];
-              }
+            for (int i = 0; i < 4; ++i) acc[gt][4 * q + i] = v1[i];
+            if (KIND == CET_RNN_GRU && gt == 2) {  // n gate keeps W_in x + b_in apart from W_hn h + b_hn
+              const f32x4 v2 = ld4(bh + gt * H + off);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[3][4 * q + i] = v2[i];
             }
           }
         }
         RP_MARK(1)
-        if (l == 0)  // encoder width / 8 valid k-blocks (2 or 4) in a segment of D
-          segment_input<KIND, D>(acc, ring, in_buf + j * in_stride + 4 * hh, a.IP / 8);
+        if (l == 0)  // ceil(features / 8) valid k-blocks in a segment of D
+          segment_input<KIND, D>(acc, ring, xin, (a.F + 7) / 8);
         else
-          segment<KIND, false, D>(acc, ring, in_buf + j * in_stride + 4 * hh, H / 8);
+          segment<KIND, false, D>(acc, ring, in_buf + j * HS + 4 * hh, H / 8);
         RP_MARK(2)
         segment<KIND, true, D>(acc, ring, hl + j * HS + 4 * hh, H / 8);
         RP_MARK(3)
@@ -458,8 +432,10 @@ __global__ __launch_bounds__(256) void rnn_rollout_kernel(const RArgs a) {
 //     follows, then every thread reads the published slices with agent-scope loads into LDS.
 //   The slices of a step go to the buffer of the step's parity; a workgroup can be at most one
 //   step ahead of the slowest one of its tile, so two buffers suffice.
-//   * the encoder and decoder Linears are small and computed redundantly by every workgroup, so
-//     the closed-loop feedback needs no further exchange.
+//   * the encoder Linear is folded into the first layer's input weights (as in the kernel above)
+//     and the decoder Linear is small and computed redundantly by every workgroup, so the
+//     closed-loop feedback needs no further exchange; a teacher-forced step's input rows are
+//     requested one step ahead.
 // Only the H / 16 workgroups of ONE sequence tile wait for each other, and the hardware starts a
 // grid's workgroups in index order (a tile's are consecutive), so a grid has at most one tile that
 // is partly resident; every complete tile runs to its end and frees its CUs. A wait can therefore
@@ -488,20 +464,26 @@ DEV f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 struct SArgs {
-  const float* w_ih[3];  // [G*H][in_l]   PyTorch layouts, device
+  // [G*H][in_l], PyTorch layout, device; layer 0 with the encoder Linear folded in: [G*H][F]
+  const float* w_ih[3];
   const float* w_hh[3];  // [G*H][H]
-  const float* bias;     // [layer][2][G*H]   (b_ih, b_hh)
-  const float* enc_w;    // [FP][FP] zero padded (row = encoder output unit)
-  const float* enc_b;    // [FP]
+  const float* bias;     // [layer][2][G*H]   (b_ih, b_hh; layer 0's b_ih with the folded encoder bias)
   const float* dec_w;    // [FP][H] zero padded (row = feature)
   const float* dec_b;    // [FP]
   const float* x;        // [B][seq][F]
   float* out;            // [B][pred][F]
   float* hx;             // exchange: [tile][layer][parity][unit group][sequence][16 units]
   unsigned* cnt;         // arrival counters [tile][layer], zero at launch
-  int B, seq_len, pred_len, F, I;
+  int B, seq_len, pred_len, F;
   int spin_limit;        // polls after which a wait gives up
+  unsigned long long* prof;  // profiling build only: [workgroup][SP_WORDS] phase times (10 ns units)
 };
+#ifdef CET_PROF
+// phases of an exchange, wave 0 lane 0: compute (from the last fetch's end to the publish store),
+// store acknowledged, counter wait, loads + LDS copy
+constexpr int SP_WORDS = 8;
+#define SP_NOW() __builtin_amdgcn_s_memrealtime()
+#endif
 
 template <int KIND, int H, int NL>
 __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
@@ -510,13 +492,12 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
   constexpr int P = H / 16;            // workgroups per sequence tile
   constexpr int HB = H / 16;           // k blocks of 16 in a hidden state
   constexpr int HS = H + 4;            // LDS row stride of a hidden state
-  constexpr int XS = FP + 4;           // LDS row stride of the input / encoder rows
-  constexpr int XB = FP / 16;          // k blocks of the (padded) encoder output and of the features
+  constexpr int XS = FP + 4;           // LDS row stride of the input rows
+  constexpr int XB = FP / 16;          // k blocks of the (padded) features
   constexpr int JX = (XB + HB + 3) / 4;  // blocks of layer 0 per wave
   constexpr int JH = (2 * HB + 3) / 4;   // blocks of a higher layer per wave
 
-  __shared__ __attribute__((aligned(16))) float xcur[ST * XS];   // this step's input features
-  __shared__ __attribute__((aligned(16))) float xe[ST * XS];     // encoder output (layer-0 input)
+  __shared__ __attribute__((aligned(16))) float xcur[ST * XS];   // this step's input features (layer-0 input)
   __shared__ __attribute__((aligned(16))) float hfull[NL][ST * HS];
   __shared__ __attribute__((aligned(16))) float part[4][NACC > 2 ? NACC : 2][256];
   __shared__ int dead;
@@ -543,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int k = 16 * b + 4 * g + i;
-          if (k < a.I) v[i] = a.w_ih[0][(size_t)row * a.I + k];
+          if (k < a.F) v[i] = a.w_ih[0][(size_t)row * a.F + k];
         }
       } else if (b < XB + HB) {
         v = ld4(a.w_hh[0] + (size_t)row * H + 16 * (b - XB) + 4 * g);
@@ -563,21 +544,16 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
         wh[l - 1][j][gt] = b < 2 * HB ? ld4(src + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-  // decoder rows (features) x this wave's k blocks of the top hidden state; encoder in wave 0
+  // decoder rows (features) x this wave's k blocks of the top hidden state
   f32x4 wd[XB][HB / 4];
 #pragma unroll
   for (int ft = 0; ft < XB; ++ft)
 #pragma unroll
     for (int j = 0; j < HB / 4; ++j)
       wd[ft][j] = ld4(a.dec_w + (size_t)(16 * ft + c) * H + 16 * (4 * j + wave) + 4 * g);
-  f32x4 we[XB][XB], be[XB], bd[XB];
+  f32x4 bd[XB];
 #pragma unroll
-  for (int it = 0; it < XB; ++it) {
-#pragma unroll
-    for (int kb = 0; kb < XB; ++kb) we[it][kb] = ld4(a.enc_w + (16 * it + c) * FP + 16 * kb + 4 * g);
-    be[it] = ld4(a.enc_b + 16 * it + 4 * g);
-    bd[it] = ld4(a.dec_b + 16 * it + 4 * g);
-  }
+  for (int it = 0; it < XB; ++it) bd[it] = ld4(a.dec_b + 16 * it + 4 * g);
   // biases of the own units (wave 0 applies them): lane (c, g) <-> units 16 ug + 4 g + i
   f32x4 bsum[NL][NACC];
 #pragma unroll
@@ -597,7 +573,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
   }
 
   for (int i = tid; i < NL * ST * HS; i += 256) (&hfull[0][0])[i] = 0.f;
-  for (int i = tid; i < ST * XS; i += 256) xcur[i] = xe[i] = 0.f;
+  for (int i = tid; i < ST * XS; i += 256) xcur[i] = 0.f;
   if (tid == 0) dead = 0;
   f32x4 hown[NL], cown[NL];  // wave 0: own slice of h (and c), units 4 g + i of sequence c
 #pragma unroll
@@ -618,7 +594,15 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
   // layer's full hidden state into hfull[l].
   // With l2 >= 0 the same for layer l2 of step t2 in the same round trip (the top layer's state of
   // the step before, whose wait was put off until its first use).
+#ifdef CET_PROF
+  unsigned long long sp[SP_WORDS] = {};
+  unsigned long long sp_t = SP_NOW();
+#define SP_MARK(i) { const unsigned long long n_ = SP_NOW(); sp[i] += n_ - sp_t; sp_t = n_; }
+#else
+#define SP_MARK(i)
+#endif
   auto fetch = [&](int l, int t, int l2 = -1, int t2 = 0) {
+    SP_MARK(2)  // publish -> fetch entry
     if (tid == 0 && !dead) {
       const unsigned target = (unsigned)P * (unsigned)(t + 1), target2 = (unsigned)P * (unsigned)(t2 + 1);
       int spins = 0;
@@ -634,6 +618,7 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
       }
     }
     __syncthreads();
+    SP_MARK(3)  // counter wait + barrier
     // thread tid takes 16 bytes (units 4 u4 .. + 3 of sequence sq) of slices tid / 64 + 4 r
     const int sq = (tid & 63) >> 2, u4 = tid & 3;
     const unsigned voff = (unsigned)(tid * 4) * 4u;  // floats (tid / 64) * 256 + sq * 16 + 4 u4 of the layer's state
@@ -656,32 +641,39 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
       for (int r = 0; r < P / 4; ++r) st4(&hfull[l2][at + 64 * r], __builtin_bit_cast(f32x4, v2[r]));
     }
     __syncthreads();
+    SP_MARK(4)  // loads + LDS copy + barrier
   };
+
+  // Teacher-forced input features: wave 0 requests a step's rows one step ahead (ST rows of up to
+  // FP floats: two 16-byte pieces per lane), so their memory latency is off the step's critical path.
+  constexpr int XPL = ST * (FP / 4) / 64;
+  const int f4n = a.F / 4;  // 16-byte pieces per row
+  f32x4 xpre[XPL];
+  auto request_x = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < XPL; ++r) {
+      const int q = lane + 64 * r;
+      if (q < ST * f4n) {
+        const int sq = q / f4n, f4 = q % f4n;
+        const int bs = b0 + sq < a.B ? b0 + sq : a.B - 1;
+        xpre[r] = ld4(a.x + ((size_t)bs * a.seq_len + t) * a.F + 4 * f4);
+      }
+    }
+  };
+  if (wave == 0) request_x(0);
 
   const int n_steps = a.seq_len + a.pred_len - 1;
   bool pending_top = false;
   for (int t = 0; t < n_steps; ++t) {
-    // ---- input features (teacher forced) and encoder Linear, wave 0 ----------------------------
-    if (wave == 0) {
-      if (t < a.seq_len) {
-        for (int q = lane; q < ST * (a.F / 4); q += 64) {
-          const int sq = q / (a.F / 4), f4 = q % (a.F / 4);
-          const int bs = b0 + sq < a.B ? b0 + sq : a.B - 1;
-          st4(xcur + sq * XS + 4 * f4, ld4(a.x + ((size_t)bs * a.seq_len + t) * a.F + 4 * f4));
-        }
+    // ---- input features of a teacher-forced step, wave 0 (a closed-loop step finds the decoder's
+    // output of the step before in xcur) -------------------------------------------------------
+    if (wave == 0 && t < a.seq_len) {
+#pragma unroll
+      for (int r = 0; r < XPL; ++r) {
+        const int q = lane + 64 * r;
+        if (q < ST * f4n) st4(xcur + (q / f4n) * XS + 4 * (q % f4n), xpre[r]);
       }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int it = 0; it < XB; ++it) {
-        f32x4 acc = be[it];
-#pragma unroll
-        for (int kb = 0; kb < XB; ++kb) {
-          const f32x4 bv = ld4(xcur + c * XS + 16 * kb + 4 * g);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = mfma16(we[it][kb][i], bv[i], acc);
-        }
-        st4(xe + c * XS + 16 * it + 4 * g, acc);
-      }
+      if (t + 1 < a.seq_len) request_x(t + 1);
     }
     __syncthreads();
 
@@ -692,32 +684,37 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
         pending_top = false;
       }
       // ---- partial gate sums over this wave's k blocks ---------------------------------------------
-      f32x4 acc[NACC];
+      // NCH accumulation chains per gate, taken in turn by the k-steps: with one wave per SIMD
+      // nothing else covers the latency of an MFMA that waits for its own accumulator (a single
+      // chain per gate ran at about 49 cycles per 32-cycle MFMA).
+      constexpr int NCH = 1;
+      f32x4 ch[NACC][NCH];
 #pragma unroll
-      for (int q = 0; q < NACC; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) ch[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // one k block of 16: B operand bv, weights wt[gate], is_x: the block belongs to the layer's input
+      auto block = [&](const f32x4 bv, const f32x4 (&wt)[G], const bool is_x) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int gt = 0; gt < G; ++gt) {
+            if (GRU && gt == 2) {  // n gate: W_in x apart from W_hn h
+              if (is_x) ch[2][i % NCH] = mfma16(wt[gt][i], bv[i], ch[2][i % NCH]);
+              else ch[3][i % NCH] = mfma16(wt[gt][i], bv[i], ch[3][i % NCH]);
+            } else {
+              ch[gt][i % NCH] = mfma16(wt[gt][i], bv[i], ch[gt][i % NCH]);
+            }
+          }
+      };
       if (l == 0) {
 #pragma unroll
         for (int j = 0; j < JX; ++j) {
           const int b = 4 * j + wave;
           if (b < XB + HB) {
             const bool is_x = b < XB;
-            const f32x4 bv = is_x ? ld4(xe + c * XS + 16 * b + 4 * g) : ld4(hfull[0] + c * HS + 16 * (b - XB) + 4 * g);
-#pragma unroll
-            for (int gt = 0; gt < G; ++gt) {
-              if (GRU && gt == 2) {
-                f32x4 ax = acc[2], ah = acc[3];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  if (is_x) ax = mfma16(w0[j][gt][i], bv[i], ax);
-                  else ah = mfma16(w0[j][gt][i], bv[i], ah);
-                }
-                acc[2] = ax;
-                acc[3] = ah;
-              } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[gt] = mfma16(w0[j][gt][i], bv[i], acc[gt]);
-              }
-            }
+            block(is_x ? ld4(xcur + c * XS + 16 * b + 4 * g) : ld4(hfull[0] + c * HS + 16 * (b - XB) + 4 * g),
+                  w0[j], is_x);
           }
         }
       } else {
@@ -726,25 +723,17 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
           const int b = 4 * j + wave;
           if (b < 2 * HB) {
             const bool is_x = b < HB;
-            const f32x4 bv = is_x ? ld4(hfull[l - 1] + c * HS + 16 * b + 4 * g) : ld4(hfull[l] + c * HS + 16 * (b - HB) + 4 * g);
-#pragma unroll
-            for (int gt = 0; gt < G; ++gt) {
-              if (GRU && gt == 2) {
-                f32x4 ax = acc[2], ah = acc[3];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  if (is_x) ax = mfma16(wh[l > 0 ? l - 1 : 0][j][gt][i], bv[i], ax);
-                  else ah = mfma16(wh[l > 0 ? l - 1 : 0][j][gt][i], bv[i], ah);
-                }
-                acc[2] = ax;
-                acc[3] = ah;
-              } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[gt] = mfma16(wh[l > 0 ? l - 1 : 0][j][gt][i], bv[i], acc[gt]);
-              }
-            }
+            block(is_x ? ld4(hfull[l - 1] + c * HS + 16 * b + 4 * g) : ld4(hfull[l] + c * HS + 16 * (b - HB) + 4 * g),
+                  wh[l > 0 ? l - 1 : 0][j], is_x);
           }
         }
+      }
+      f32x4 acc[NACC];
+#pragma unroll
+      for (int q = 0; q < NACC; ++q) {
+        acc[q] = ch[q][0];
+#pragma unroll
+        for (int n = 1; n < NCH; ++n) acc[q] += ch[q][n];
       }
 #pragma unroll
       for (int q = 0; q < NACC; ++q) st4(&part[wave][q][4 * lane], acc[q]);
@@ -779,10 +768,12 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
           hn[i] = hv;
         }
         hown[l] = hn;
+        SP_MARK(0)  // matrix work, partial sums, cell update
         // units 4 g .. + 3 of sequence c: one 16-byte store per lane, the slice's 1 KiB in whole lines
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hn), hx_rsrc, (unsigned)(c * 16 + 4 * g) * 4u,
                                                (unsigned)(((l * 2 + (t & 1)) * P + ug) * 256) * 4u, AGENT_SCOPE);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SP_MARK(1)  // store acknowledged
         if (lane == 0)
           __hip_atomic_fetch_add(cnt_tile + l * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -827,11 +818,17 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
             st4(a.out + ((size_t)(b0 + c) * a.pred_len + (t - (a.seq_len - 1))) * a.F + f0, y);
         }
       }
-      // the next step's barrier orders these LDS writes before the encoder reads them (wave 0 does
-      // both) and the reads of `part` before it is written again
+      // the next step's barrier orders these LDS writes before layer 0 reads them and the reads of
+      // `part` before it is written again
     }
   }
   (void)bc;
+#ifdef CET_PROF
+  if (tid == 0 && a.prof) {
+    SP_MARK(5)
+    for (int i = 0; i < SP_WORDS; ++i) a.prof[(size_t)blockIdx.x * SP_WORDS + i] = sp[i];
+  }
+#endif
   // A wait that ran out anywhere in the grid (the workgroups were not all resident: the GPU was
   // shared with other work) leaves garbage in the exchange. The predictions are then overwritten
   // with NaN, so that such a rollout cannot pass for a result.
@@ -863,10 +860,12 @@ static __device__ __align__(256) float g_split_scratch[SPLIT_MAX_FLOATS];
 // Host side
 
 struct RnnModel {
-  int kind, F, I, H, layers, IP;
+  int kind, F, I, H, layers;
   float* dev = nullptr;  // one allocation; the pointers below point into it
-  const float *wstream, *bias, *enc_w, *enc_b, *dec_w, *dec_b;
-  const float *w_ih[3], *w_hh[3];  // gate weights in their PyTorch layouts (hidden-split kernel)
+  // bias: SArgs::bias (hidden-split kernel); bias_tiled: RArgs::bias
+  const float *wstream, *bias, *bias_tiled, *dec_w, *dec_b;
+  // gate weights in their PyTorch layouts (hidden-split kernel); w_ih[0] with the encoder folded in
+  const float *w_ih[3], *w_hh[3];
   int device = 0, cus = 0;
   // 0: by batch size, 1: batch-tiled kernel, 2: hidden-split kernel, 3: hidden-split kernel whose
   // exchange gives up at its first unanswered poll (tests: exercises the stand-by launch)
@@ -907,7 +906,7 @@ static bool rnn_supported(int kind, int F, int I, int H, int layers) {
   if (H != 128 && H != 256) return false;
   if (layers < 1 || layers > 3) return false;
   if (F < 4 || F > FP || F % 4) return false;
-  if (I < 1 || I > FP) return false;
+  if (I < 1 || I > 4096) return false;  // folded into the first layer at create time: any width
   return true;
 }
 
@@ -932,27 +931,47 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   if (!rnn_supported(kind, F, I, H, layers)) return CET_ERR_UNSUPPORTED;
   if (n != rnn_blob_size(kind, F, I, H, layers)) return CET_ERR_BLOB_SIZE;
   const int G = gates_of(kind);
-  const int IP = (I + 15) / 16 * 16;
   const int UT = H / 128;
 
   const float* p = w;
   const float* enc_w = p; p += (size_t)I * F;
   const float* enc_b = p; p += I;
   const int D = ring_depth(kind);
-  if (IP / 8 > D || IP / 8 > 4 || (H / 8) % D) return CET_ERR_UNSUPPORTED;
-  struct LayerW { const float *w_ih, *w_hh; int in, in_p; };
+  if (D < 4 || (H / 8) % D) return CET_ERR_UNSUPPORTED;  // up to 4 k-blocks of features in a segment of D
+  struct LayerW { const float *w_ih, *w_hh; int in; };
   std::vector<LayerW> lw;
-  std::vector<float> stream, bias;
+  std::vector<float> stream, bias, bias_tiled;
+  // The encoder Linear folded into the first layer for the batch-tiled kernel:
+  // W_ih0 (We x + be) + b_ih0 = (W_ih0 We) x + (W_ih0 be + b_ih0), accumulated in double.
+  std::vector<float> w_fold((size_t)G * H * F), b_fold((size_t)G * H);
   for (int l = 0; l < layers; ++l) {
-    const int in = l == 0 ? I : H;          // true input width
-    const int in_p = l == 0 ? IP : H;       // padded (zero weights beyond `in`)
+    const int in = l == 0 ? I : H;          // input width
     const float* w_ih = p; p += (size_t)G * H * in;
     const float* w_hh = p; p += (size_t)G * H * H;
     const float* b_ih = p; p += (size_t)G * H;
     const float* b_hh = p; p += (size_t)G * H;
-    bias.insert(bias.end(), b_ih, b_ih + (size_t)G * H);
+    if (l == 0) {
+      for (int r = 0; r < G * H; ++r) {
+        double bs = b_ih[r];
+        for (int k = 0; k < I; ++k) bs += (double)w_ih[(size_t)r * I + k] * (double)enc_b[k];
+        b_fold[r] = (float)bs;
+        for (int c = 0; c < F; ++c) {
+          double ws = 0.0;
+          for (int k = 0; k < I; ++k) ws += (double)w_ih[(size_t)r * I + k] * (double)enc_w[(size_t)k * F + c];
+          w_fold[(size_t)r * F + c] = (float)ws;
+        }
+      }
+    }
+    // b_ih + b_hh where the cell adds them anyway; the GRU's n gate (rows 2 H .. 3 H) keeps both
+    const float* bi = l == 0 ? b_fold.data() : b_ih;
+    bias.insert(bias.end(), bi, bi + (size_t)G * H);
     bias.insert(bias.end(), b_hh, b_hh + (size_t)G * H);
-    lw.push_back({w_ih, w_hh, in, in_p});
+    for (int part = 0; part < 2; ++part)
+      for (int r = 0; r < G * H; ++r) {
+        const bool apart = kind == CET_RNN_GRU && r >= 2 * H;
+        bias_tiled.push_back(part == 0 ? (apart ? bi[r] : bi[r] + b_hh[r]) : (apart ? b_hh[r] : 0.f));
+      }
+    lw.push_back({w_ih, w_hh, in});
   }
   // one stream per wave in consumption order: [layer][unit tile][input segment | hidden segment]
   // [k-block][gate][64 lanes][4]; the layer-0 input segment is padded to D k-blocks
@@ -960,8 +979,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     for (int l = 0; l < layers; ++l)
       for (int u = 0; u < UT; ++u)
         for (int part = 0; part < 2; ++part) {
-          const float* W = part == 0 ? lw[l].w_ih : lw[l].w_hh;
-          const int K = part == 0 ? lw[l].in : H;
+          const float* W = part == 0 ? (l == 0 ? w_fold.data() : lw[l].w_ih) : lw[l].w_hh;
+          const int K = part == 0 ? (l == 0 ? F : H) : H;
           const int nblk = part == 0 ? (l == 0 ? D : H / 8) : H / 8;
           for (int kb = 0; kb < nblk; ++kb)
             for (int g = 0; g < G; ++g)
@@ -976,11 +995,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   const float* dec_b = p; p += F;
   if ((size_t)(p - w) != n) return CET_ERR_BLOB_SIZE;
 
-  std::vector<float> ew((size_t)FP * FP, 0.f), eb(FP, 0.f), dw((size_t)FP * H, 0.f), db(FP, 0.f);
-  for (int r = 0; r < I; ++r) {
-    for (int c = 0; c < F; ++c) ew[(size_t)r * FP + c] = enc_w[(size_t)r * F + c];
-    eb[r] = enc_b[r];
-  }
+  std::vector<float> dw((size_t)FP * H, 0.f), db(FP, 0.f);
   for (int r = 0; r < F; ++r) {
     for (int c = 0; c < H; ++c) dw[(size_t)r * H + c] = dec_w[(size_t)r * H + c];
     db[r] = dec_b[r];
@@ -988,7 +1003,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
 
   RnnModel* m = new (std::nothrow) RnnModel;
   if (!m) return CET_ERR_ALLOC;
-  m->kind = kind; m->F = F; m->I = I; m->H = H; m->layers = layers; m->IP = IP;
+  m->kind = kind; m->F = F; m->I = I; m->H = H; m->layers = layers;
   std::vector<float> all;
   auto place = [&](const std::vector<float>& v) {
     const size_t off = all.size();
@@ -996,11 +1011,11 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     while (all.size() % 64) all.push_back(0.f);  // keep every block 256-byte aligned
     return off;
   };
-  const size_t o_stream = place(stream), o_bias = place(bias), o_ew = place(ew), o_eb = place(eb),
+  const size_t o_stream = place(stream), o_bias = place(bias), o_bias_t = place(bias_tiled),
                o_dw = place(dw), o_db = place(db);
   size_t o_ih[3] = {0, 0, 0}, o_hh[3] = {0, 0, 0};
   for (int l = 0; l < layers; ++l) {
-    o_ih[l] = place(std::vector<float>(lw[l].w_ih, lw[l].w_ih + (size_t)G * H * lw[l].in));
+    o_ih[l] = place(l == 0 ? w_fold : std::vector<float>(lw[l].w_ih, lw[l].w_ih + (size_t)G * H * lw[l].in));
     o_hh[l] = place(std::vector<float>(lw[l].w_hh, lw[l].w_hh + (size_t)G * H * H));
   }
   hipError_t e = hipMalloc(&m->dev, all.size() * sizeof(float));
@@ -1011,8 +1026,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     delete m;
     return hip_fail(e);
   }
-  m->wstream = m->dev + o_stream; m->bias = m->dev + o_bias; m->enc_w = m->dev + o_ew;
-  m->enc_b = m->dev + o_eb; m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
+  m->wstream = m->dev + o_stream; m->bias = m->dev + o_bias; m->bias_tiled = m->dev + o_bias_t;
+  m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
   for (int l = 0; l < 3; ++l) {
     m->w_ih[l] = l < layers ? m->dev + o_ih[l] : nullptr;
     m->w_hh[l] = l < layers ? m->dev + o_hh[l] : nullptr;
@@ -1036,8 +1051,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
 template <int KIND, int UT, int NL>
 static size_t lds_bytes() {
   constexpr int H = 128 * UT;
-  return sizeof(float) * (size_t)(BT * PSTR * 5 + NL * BT * (H + 4) + NL * 2 * Cell<KIND>::G * H +
-                                  FP * PSTR + FP);
+  return sizeof(float) * (size_t)(BT * PSTR * 4 + NL * BT * (H + 4) + NL * 2 * Cell<KIND>::G * H);
 }
 
 // Once per handle, on the handle's device: the kernel's dynamic LDS exceeds the default limit.
@@ -1117,9 +1131,9 @@ static bool split_fits(const RnnModel* m, int B, int max_wg) {
 
 static RArgs tiled_args(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len) {
   RArgs a{};
-  a.wstream = m->wstream; a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b;
+  a.wstream = m->wstream; a.bias = m->bias_tiled;
   a.dec_w = m->dec_w; a.dec_b = m->dec_b; a.x = x; a.out = out;
-  a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F; a.IP = m->IP;
+  a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F;
   return a;
 }
 
@@ -1134,12 +1148,19 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
     a.w_ih[l] = m->w_ih[l];
     a.w_hh[l] = m->w_hh[l];
   }
-  a.bias = m->bias; a.enc_w = m->enc_w; a.enc_b = m->enc_b; a.dec_w = m->dec_w; a.dec_b = m->dec_b;
-  a.x = x; a.out = out; a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F; a.I = m->I;
+  a.bias = m->bias; a.dec_w = m->dec_w; a.dec_b = m->dec_b;
+  a.x = x; a.out = out; a.B = B; a.seq_len = seq_len; a.pred_len = pred_len; a.F = m->F;
   a.cnt = reinterpret_cast<unsigned*>(scratch);
   a.hx = scratch + SPLIT_CNT_FLOATS;
   CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
   const int tiles = split_tiles(B);
+#ifdef CET_PROF
+  static unsigned long long* sp_dev = nullptr;
+  const int sp_wg = tiles * (m->H / 16);
+  if (!sp_dev) CET_HIP(hipMalloc(&sp_dev, 1024 * SP_WORDS * sizeof(unsigned long long)));
+  CET_HIP(hipMemsetAsync(sp_dev, 0, 1024 * SP_WORDS * sizeof(unsigned long long), stream));
+  a.prof = sp_wg <= 1024 ? sp_dev : nullptr;
+#endif
   int rc;
   switch (m->kind) {
     case CET_RNN_TANH: rc = launch_split_kind<CET_RNN_TANH>(m, a, tiles, stream); break;
@@ -1147,6 +1168,25 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
     default: rc = launch_split_kind<CET_RNN_LSTM>(m, a, tiles, stream); break;
   }
   if (rc != CET_OK) return rc;
+#ifdef CET_PROF
+  if (a.prof && getenv("CET_SPLIT_PROF")) {
+    static unsigned long long h[1024 * SP_WORDS];
+    CET_HIP(hipStreamSynchronize(stream));
+    CET_HIP(hipMemcpy(h, sp_dev, sizeof h, hipMemcpyDeviceToHost));
+    static const char* names[6] = {"matrix work + cell update", "publish store acknowledged", "publish -> fetch entry",
+                                   "counter wait + barrier", "loads + LDS copy + barrier", "rest (decode, input)"};
+    const int ex = (seq_len + pred_len - 1) * m->layers;
+    for (int i = 0; i < 6; ++i) {
+      double sum = 0, mx = 0;
+      for (int w = 0; w < sp_wg; ++w) {
+        sum += (double)h[w * SP_WORDS + i];
+        if ((double)h[w * SP_WORDS + i] > mx) mx = (double)h[w * SP_WORDS + i];
+      }
+      fprintf(stderr, "[cet split prof] %-28s mean %7.3f us  max %7.3f us per layer step (B %d, %d workgroups)\n",
+              names[i], sum / sp_wg / ex * 0.01, mx / ex * 0.01, B, sp_wg);
+    }
+  }
+#endif
   RArgs t = tiled_args(m, x, out, B, seq_len, pred_len);
   t.only_if = a.cnt + (SPLIT_CNT_FLOATS - 1);
   PrepareFn pf;

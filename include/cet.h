@@ -138,7 +138,9 @@ size_t cet_rnn_blob_size(int kind, int features, int input_size, int hidden_size
 
 /* Stands in for `GRU/LSTM/RNN(features, input_size, hidden_size, num_layers)` +
  * `load_state_dict` + `.eval()` (LocalSimulations/models/model.py:276, 350, 426;
- * HPC/python/Evaluate.py:60-98). `weights` is a HOST pointer. */
+ * HPC/python/Evaluate.py:60-98). `weights` is a HOST pointer. Supported: features a multiple of
+ * 4 up to 32, hidden_size 128 or 256, 1 to 3 layers, input_size 1 to 4096 (the encoder Linear is
+ * folded into the first layer's input weights at create time, in double precision). */
 int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int num_layers,
                    const float* weights, size_t n_weights, cet_handle* out);
 

@@ -116,7 +116,8 @@ def test_long_horizon_rollout(name, variant, oracle):
 
 
 SWEEP = [(cls, F, I, H, layers) for cls in ("RNN", "GRU", "LSTM")
-         for (F, I, H, layers) in ((16, 16, 128, 1), (32, 32, 256, 3), (8, 24, 128, 2), (16, 32, 256, 1))]
+         for (F, I, H, layers) in ((16, 16, 128, 1), (32, 32, 256, 3), (8, 24, 128, 2), (16, 32, 256, 1),
+                                   (16, 64, 128, 2), (4, 100, 256, 2), (32, 7, 128, 1))]  # any encoder width
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -1,0 +1,17 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import channelestimationtransformer_amd as cet
+from channelestimationtransformer_amd import synth
+for name in ("GRU", "RNN"):
+    m = getattr(cet, name)(16, 32, 256, 2).eval().select_kernel("split")
+    for B in (16, 256):
+        noisy, _ = synth.channel_histories(B, seed=1)
+        x = cet.LoadBatch(noisy[:, :25]).cuda()
+        for _ in range(3):
+            m.test_data(x, 5, "cuda")
+        torch.cuda.synchronize()
+        os.environ["CET_SPLIT_PROF"] = "1"
+        print(name, B, flush=True)
+        m.test_data(x, 5, "cuda")
+        torch.cuda.synchronize()
+        del os.environ["CET_SPLIT_PROF"]
