@@ -485,21 +485,40 @@ constexpr int SP_WORDS = 8;
 #define SP_NOW() __builtin_amdgcn_s_memrealtime()
 #endif
 
-template <int KIND, int H, int NL>
+// UW: hidden units per workgroup (16, 8 or 4), P = H / UW workgroups per sequence tile. The rows of
+// a layer's gate product are NACC groups of UW units (tanh cell: h; GRU: r, z, n from the input, n
+// from the state; LSTM: i, f, g, o), row = group * UW + unit, in tiles of 16 rows. With 16 units a
+// group is a tile; with 4 units the four groups of a GRU or LSTM share one tile, so a workgroup
+// issues a quarter of the MFMAs per layer step (128 instead of 384 / 512 at 256 hidden units) and a
+// batch of up to 64 sequences spreads over four times as many CUs. The launcher picks the
+// smallest UW whose grid fits the device.
+template <int KIND, int H, int NL, int UW>
 __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
   constexpr int G = Cell<KIND>::G, NACC = Cell<KIND>::NACC;
   constexpr bool LSTM = KIND == CET_RNN_LSTM, GRU = KIND == CET_RNN_GRU;
-  constexpr int P = H / 16;            // workgroups per sequence tile
+  constexpr int P = H / UW;            // workgroups per sequence tile
+  // Arrival counters of a (tile, layer): one per 16 workgroups, each in a line of its own (64 arrivals
+  // on one word took 0.55 us longer per layer step than 16)
+  constexpr int NS = P > 16 ? P / 16 : 1;
+  constexpr int UPL = UW / 4;          // units per lane in the cell update: lane (c, g) <-> units g UPL + e
+  constexpr int NT = (NACC * UW + 15) / 16;  // row tiles of the gate product
+  // 16 units: the GRU's two n groups (input part, state part) have the same rows, so they share a
+  // set of weight registers; a block of the input feeds one accumulator, a block of the state the other
+  constexpr bool SHARE_N = GRU && UW == 16;
+  constexpr int NTW = SHARE_N ? 3 : NT;  // weight register sets per k block
+  constexpr int NA = SHARE_N ? 4 : NT;   // accumulators
   constexpr int HB = H / 16;           // k blocks of 16 in a hidden state
   constexpr int HS = H + 4;            // LDS row stride of a hidden state
   constexpr int XS = FP + 4;           // LDS row stride of the input rows
   constexpr int XB = FP / 16;          // k blocks of the (padded) features
   constexpr int JX = (XB + HB + 3) / 4;  // blocks of layer 0 per wave
   constexpr int JH = (2 * HB + 3) / 4;   // blocks of a higher layer per wave
+  static_assert(UW == 4 || UW == 8 || UW == 16, "units per workgroup");
 
   __shared__ __attribute__((aligned(16))) float xcur[ST * XS];   // this step's input features (layer-0 input)
   __shared__ __attribute__((aligned(16))) float hfull[NL][ST * HS];
-  __shared__ __attribute__((aligned(16))) float part[4][NACC > 2 ? NACC : 2][256];
+  __shared__ __attribute__((aligned(16))) float part[4][NA > 2 ? NA : 2][256];
+  __shared__ __attribute__((aligned(16))) float pub[ST * UW];    // the own slice on its way out (UW < 16)
   __shared__ int dead;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -511,26 +530,33 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
 
   // ---- this wave's weights, in registers for the whole rollout --------------------------------
   // Block b of a layer covers k = 16 b .. 16 b + 15 of [input ; hidden]; wave w owns blocks
-  // 4 j + w. Lane (c, g) holds, per gate, W[unit 16 ug + c][k = 16 b + 4 g + i], i = 0..3.
-  f32x4 w0[JX][G], wh[NL > 1 ? NL - 1 : 1][JH][G];
+  // 4 j + w. Lane (c, g) holds, per row tile m, W[row 16 m + c][k = 16 b + 4 g + i], i = 0..3:
+  // zero for rows beyond the groups and, where the GRU's n groups have rows of their own, for the
+  // input-part group in a block of the state and the other way round.
+  auto wload = [&](int l, int m, bool x_block, int k0, int in) {
+    const int r = 16 * m + c, grp = r / UW, unit = r % UW;
+    int gate = grp;
+    bool valid = r < NACC * UW;
+    if (GRU) {
+      gate = grp < 2 ? grp : 2;
+      if (!SHARE_N) valid = valid && !(grp == 2 && !x_block) && !(grp == 3 && x_block);
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int width = x_block ? in : H;  // a multiple of 4
+    if (valid && k0 + 4 * g < width) {
+      const size_t row = (size_t)gate * H + UW * ug + unit;
+      v = ld4((x_block ? a.w_ih[l] + row * in : a.w_hh[l] + row * H) + k0 + 4 * g);
+    }
+    return v;
+  };
+  f32x4 w0[JX][NTW], wh[NL > 1 ? NL - 1 : 1][JH][NTW];
 #pragma unroll
   for (int j = 0; j < JX; ++j) {
     const int b = 4 * j + wave;
 #pragma unroll
-    for (int gt = 0; gt < G; ++gt) {
-      const int row = gt * H + 16 * ug + c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b < XB) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = 16 * b + 4 * g + i;
-          if (k < a.F) v[i] = a.w_ih[0][(size_t)row * a.F + k];
-        }
-      } else if (b < XB + HB) {
-        v = ld4(a.w_hh[0] + (size_t)row * H + 16 * (b - XB) + 4 * g);
-      }
-      w0[j][gt] = v;
-    }
+    for (int m = 0; m < NTW; ++m)
+      w0[j][m] = b < XB ? wload(0, m, true, 16 * b, a.F)
+                        : (b < XB + HB ? wload(0, m, false, 16 * (b - XB), a.F) : f32x4{0.f, 0.f, 0.f, 0.f});
   }
 #pragma unroll
   for (int l = 1; l < NL; ++l)
@@ -538,11 +564,9 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
     for (int j = 0; j < JH; ++j) {
       const int b = 4 * j + wave;
 #pragma unroll
-      for (int gt = 0; gt < G; ++gt) {
-        const int row = gt * H + 16 * ug + c;
-        const float* src = b < HB ? a.w_ih[l] + (size_t)row * H + 16 * b : a.w_hh[l] + (size_t)row * H + 16 * (b - HB);
-        wh[l - 1][j][gt] = b < 2 * HB ? ld4(src + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int m = 0; m < NTW; ++m)
+        wh[l - 1][j][m] = b < HB ? wload(l, m, true, 16 * b, H)
+                                 : (b < 2 * HB ? wload(l, m, false, 16 * (b - HB), H) : f32x4{0.f, 0.f, 0.f, 0.f});
     }
   // decoder rows (features) x this wave's k blocks of the top hidden state
   f32x4 wd[XB][HB / 4];
@@ -554,40 +578,44 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
   f32x4 bd[XB];
 #pragma unroll
   for (int it = 0; it < XB; ++it) bd[it] = ld4(a.dec_b + 16 * it + 4 * g);
-  // biases of the own units (wave 0 applies them): lane (c, g) <-> units 16 ug + 4 g + i
-  f32x4 bsum[NL][NACC];
+  // biases of the own units (wave 0 applies them): lane (c, g) <-> units UW ug + g UPL + e
+  float bsum[NL][NACC][UPL];
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     const float* bi = a.bias + (size_t)l * 2 * G * H;
     const float* bh = bi + G * H;
 #pragma unroll
-    for (int gt = 0; gt < G; ++gt) {
-      const f32x4 v1 = ld4(bi + gt * H + 16 * ug + 4 * g), v2 = ld4(bh + gt * H + 16 * ug + 4 * g);
-      if (GRU && gt == 2) {
-        bsum[l][2] = v1;  // n gate: W_in x + b_in apart from W_hn h + b_hn
-        bsum[l][3] = v2;
-      } else {
-        bsum[l][gt] = v1 + v2;
+    for (int gt = 0; gt < G; ++gt)
+#pragma unroll
+      for (int e = 0; e < UPL; ++e) {
+        const int u = gt * H + UW * ug + g * UPL + e;
+        if (GRU && gt == 2) {
+          bsum[l][2][e] = bi[u];  // n gate: W_in x + b_in apart from W_hn h + b_hn
+          bsum[l][3][e] = bh[u];
+        } else {
+          bsum[l][gt][e] = bi[u] + bh[u];
+        }
       }
-    }
   }
 
   for (int i = tid; i < NL * ST * HS; i += 256) (&hfull[0][0])[i] = 0.f;
   for (int i = tid; i < ST * XS; i += 256) xcur[i] = 0.f;
   if (tid == 0) dead = 0;
-  f32x4 hown[NL], cown[NL];  // wave 0: own slice of h (and c), units 4 g + i of sequence c
+  float hown[NL][UPL], cown[NL][UPL];  // wave 0: own slice of h (and c), units g UPL + e of sequence c
 #pragma unroll
-  for (int l = 0; l < NL; ++l) hown[l] = cown[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < NL; ++l)
+#pragma unroll
+    for (int e = 0; e < UPL; ++e) hown[l][e] = cown[l][e] = 0.f;
   __syncthreads();
 
-  // The tile's exchange area [layer][parity][unit group][sequence][16 units] through a buffer
+  // The tile's exchange area [layer][parity][unit group][sequence][UW units] through a buffer
   // descriptor: 16-byte agent-scope (sc1, write-through / L1-bypassing) stores and loads, a quarter
   // of the instructions of 4-byte ones and, for the stores, a sixth of their time per byte.
   const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.hx + (size_t)tile * NL * 2 * P * 256, 0, NL * 2 * P * 256 * 4, 0x00020000);
+      a.hx + (size_t)tile * NL * 2 * H * ST, 0, NL * 2 * H * ST * 4, 0x00020000);
   constexpr int AGENT_SCOPE = 16;  // sc1
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  unsigned* const cnt_tile = a.cnt + (size_t)tile * NL * CNT_STRIDE;
+  unsigned* const cnt_tile = a.cnt + (size_t)tile * NL * NS * CNT_STRIDE;  // [layer][shard]
   unsigned* const fail = a.cnt + (SPLIT_CNT_FLOATS - 1);  // set by any workgroup whose wait ran out
 
   // Waits until every workgroup of the tile has published layer l of step t, then copies the
@@ -601,44 +629,69 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
 #else
 #define SP_MARK(i)
 #endif
+  // The arrival at a layer's counter follows the acknowledgement of the slice's stores. For the top
+  // layer of a step whose prediction is not needed, nobody waits for that arrival before the next
+  // step's first layer has been computed, so it is put off until then (wave 0; `pend`: the layer)
+  // and the wait for the acknowledgement costs nothing.
+  int pend = -1;
+  auto arrive_flush = [&]() {
+    if (wave == 0 && pend >= 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_fetch_add(cnt_tile + (pend * NS + ug % NS) * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pend = -1;
+    }
+  };
   auto fetch = [&](int l, int t, int l2 = -1, int t2 = 0) {
+    arrive_flush();
     SP_MARK(2)  // publish -> fetch entry
-    if (tid == 0 && !dead) {
-      const unsigned target = (unsigned)P * (unsigned)(t + 1), target2 = (unsigned)P * (unsigned)(t2 + 1);
+    if (wave == 0 && !dead) {  // lane s < NS polls shard s; the wave leaves when every shard has arrived
+      const unsigned target = (unsigned)(P / NS) * (unsigned)(t + 1), target2 = (unsigned)(P / NS) * (unsigned)(t2 + 1);
+      const int sh = lane < NS ? lane : 0;
       int spins = 0;
-      while (__hip_atomic_load(cnt_tile + l * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target ||
-             (l2 >= 0 &&
-              __hip_atomic_load(cnt_tile + l2 * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target2)) {
+      for (;;) {
+        bool ok = __hip_atomic_load(cnt_tile + (l * NS + sh) * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        if (l2 >= 0)
+          ok = ok && __hip_atomic_load(cnt_tile + (l2 * NS + sh) * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target2;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > a.spin_limit) {
-          dead = 1;
-          __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) {
+            dead = 1;
+            __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           break;
         }
       }
     }
     __syncthreads();
     SP_MARK(3)  // counter wait + barrier
-    // thread tid takes 16 bytes (units 4 u4 .. + 3 of sequence sq) of slices tid / 64 + 4 r
-    const int sq = (tid & 63) >> 2, u4 = tid & 3;
-    const unsigned voff = (unsigned)(tid * 4) * 4u;  // floats (tid / 64) * 256 + sq * 16 + 4 u4 of the layer's state
-    const unsigned so = (unsigned)((l * 2 + (t & 1)) * P * 256) * 4u;
-    const unsigned so2 = (unsigned)(((l2 >= 0 ? l2 : 0) * 2 + (t2 & 1)) * P * 256) * 4u;
-    u32x4 v[P / 4], v2[P / 4];  // all loads of the round in flight together: one memory round trip
+    // A layer's state is H ST / 4 pieces of 16 bytes; piece p = (unit group, sequence, four units)
+    // in the order they lie in the exchange area; thread tid takes pieces tid + 256 r.
+    constexpr int NPC = H * ST / 4 / 256;
+    const unsigned voff = (unsigned)(tid * 4) * 4u;
+    const unsigned so = (unsigned)((l * 2 + (t & 1)) * H * ST) * 4u;
+    const unsigned so2 = (unsigned)(((l2 >= 0 ? l2 : 0) * 2 + (t2 & 1)) * H * ST) * 4u;
+    u32x4 v[NPC], v2[NPC];  // all loads of the round in flight together: one memory round trip
 #pragma unroll
-    for (int r = 0; r < P / 4; ++r)
+    for (int r = 0; r < NPC; ++r)
       v[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, voff + (unsigned)(r * 4 * 256 * 4), so, AGENT_SCOPE);
     if (l2 >= 0) {
 #pragma unroll
-      for (int r = 0; r < P / 4; ++r)
+      for (int r = 0; r < NPC; ++r)
         v2[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, voff + (unsigned)(r * 4 * 256 * 4), so2, AGENT_SCOPE);
     }
-    const int at = sq * HS + 16 * (tid >> 6) + 4 * u4;
+    int at[NPC];
 #pragma unroll
-    for (int r = 0; r < P / 4; ++r) st4(&hfull[l][at + 64 * r], __builtin_bit_cast(f32x4, v[r]));
+    for (int r = 0; r < NPC; ++r) {
+      const int p = tid + 256 * r, q = p % (4 * UW);
+      at[r] = (q / UPL) * HS + UW * (p / (4 * UW)) + 4 * (q % UPL);
+    }
+#pragma unroll
+    for (int r = 0; r < NPC; ++r) st4(&hfull[l][at[r]], __builtin_bit_cast(f32x4, v[r]));
     if (l2 >= 0) {
 #pragma unroll
-      for (int r = 0; r < P / 4; ++r) st4(&hfull[l2][at + 64 * r], __builtin_bit_cast(f32x4, v2[r]));
+      for (int r = 0; r < NPC; ++r) st4(&hfull[l2][at[r]], __builtin_bit_cast(f32x4, v2[r]));
     }
     __syncthreads();
     SP_MARK(4)  // loads + LDS copy + barrier
@@ -684,26 +737,21 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
         pending_top = false;
       }
       // ---- partial gate sums over this wave's k blocks ---------------------------------------------
-      // NCH accumulation chains per gate, taken in turn by the k-steps: with one wave per SIMD
-      // nothing else covers the latency of an MFMA that waits for its own accumulator (a single
-      // chain per gate ran at about 49 cycles per 32-cycle MFMA).
-      constexpr int NCH = 1;
-      f32x4 ch[NACC][NCH];
+      f32x4 acc[NA];
 #pragma unroll
-      for (int q = 0; q < NACC; ++q)
-#pragma unroll
-        for (int n = 0; n < NCH; ++n) ch[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // one k block of 16: B operand bv, weights wt[gate], is_x: the block belongs to the layer's input
-      auto block = [&](const f32x4 bv, const f32x4 (&wt)[G], const bool is_x) {
+      for (int q = 0; q < NA; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // one k block of 16: B operand bv, weights wt[row tile], is_x: the block belongs to the layer's
+      // input; the row tiles take turns so that consecutive MFMAs do not wait for each other
+      auto block = [&](const f32x4 bv, const f32x4 (&wt)[NTW], const bool is_x) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int gt = 0; gt < G; ++gt) {
-            if (GRU && gt == 2) {  // n gate: W_in x apart from W_hn h
-              if (is_x) ch[2][i % NCH] = mfma16(wt[gt][i], bv[i], ch[2][i % NCH]);
-              else ch[3][i % NCH] = mfma16(wt[gt][i], bv[i], ch[3][i % NCH]);
+          for (int m = 0; m < NTW; ++m) {
+            if (SHARE_N && m == 2) {  // n gate: W_in x apart from W_hn h
+              if (is_x) acc[2] = mfma16(wt[m][i], bv[i], acc[2]);
+              else acc[NA - 1] = mfma16(wt[m][i], bv[i], acc[NA - 1]);
             } else {
-              ch[gt][i % NCH] = mfma16(wt[gt][i], bv[i], ch[gt][i % NCH]);
+              acc[m] = mfma16(wt[m][i], bv[i], acc[m]);
             }
           }
       };
@@ -728,54 +776,66 @@ __global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
           }
         }
       }
-      f32x4 acc[NACC];
 #pragma unroll
-      for (int q = 0; q < NACC; ++q) {
-        acc[q] = ch[q][0];
-#pragma unroll
-        for (int n = 1; n < NCH; ++n) acc[q] += ch[q][n];
-      }
-#pragma unroll
-      for (int q = 0; q < NACC; ++q) st4(&part[wave][q][4 * lane], acc[q]);
+      for (int q = 0; q < NA; ++q) st4(&part[wave][q][4 * lane], acc[q]);
       __syncthreads();
-      // ---- cell update of the own 16 x 16 slice and its publication, wave 0 --------------------------
+      // ---- cell update of the own UW x 16 slice and its publication, wave 0 --------------------------
       if (wave == 0) {
-        f32x4 s[NACC];
+        // group q of this lane's units: rows q UW + g UPL + e of the gate product, i.e. row rr of tile m,
+        // which the lanes (rr / 4, c) of every wave hold in register rr % 4 of accumulator m
+        float s[NACC][UPL];
 #pragma unroll
-        for (int q = 0; q < NACC; ++q)
-          s[q] = ((ld4(&part[0][q][4 * lane]) + ld4(&part[1][q][4 * lane])) +
-                  (ld4(&part[2][q][4 * lane]) + ld4(&part[3][q][4 * lane]))) + bsum[l][q];
-        f32x4 hn;
+        for (int q = 0; q < NACC; ++q) {
+          const int r0 = q * UW + g * UPL, m = r0 / 16, rr = r0 % 16;
+          const int off = 4 * (16 * (rr / 4) + c) + rr % 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+          for (int e = 0; e < UPL; ++e)
+            s[q][e] = ((part[0][m][off + e] + part[1][m][off + e]) + (part[2][m][off + e] + part[3][m][off + e])) +
+                      bsum[l][q][e];
+        }
+        float hn[UPL];
+#pragma unroll
+        for (int e = 0; e < UPL; ++e) {
           float hv;
           if (KIND == CET_RNN_TANH) {
-            hv = tanhf_(s[0][i]);
+            hv = tanhf_(s[0][e]);
           } else if (GRU) {
-            const float rg = sigmoidf_(s[0][i]);
-            const float zg = sigmoidf_(s[1][i]);
-            const float ng = tanhf_(s[2][i] + rg * s[3][i]);
-            hv = (1.0f - zg) * ng + zg * hown[l][i];
+            const float rg = sigmoidf_(s[0][e]);
+            const float zg = sigmoidf_(s[1][e]);
+            const float ng = tanhf_(s[2][e] + rg * s[NACC - 1][e]);
+            hv = (1.0f - zg) * ng + zg * hown[l][e];
           } else {
-            const float ig = sigmoidf_(s[0][i]);
-            const float fg = sigmoidf_(s[1][i]);
-            const float gg = tanhf_(s[2][i]);
-            const float og = sigmoidf_(s[LSTM ? 3 : 0][i]);
-            const float cv = __fadd_rn(__fmul_rn(fg, cown[l][i]), __fmul_rn(ig, gg));
-            cown[l][i] = cv;
+            const float ig = sigmoidf_(s[0][e]);
+            const float fg = sigmoidf_(s[1][e]);
+            const float gg = tanhf_(s[LSTM ? 2 : 0][e]);
+            const float og = sigmoidf_(s[LSTM ? 3 : 0][e]);
+            const float cv = __fadd_rn(__fmul_rn(fg, cown[l][e]), __fmul_rn(ig, gg));
+            cown[l][e] = cv;
             hv = og * tanhf_(cv);
           }
-          hn[i] = hv;
+          hn[e] = hv;
+          hown[l][e] = hv;
         }
-        hown[l] = hn;
         SP_MARK(0)  // matrix work, partial sums, cell update
-        // units 4 g .. + 3 of sequence c: one 16-byte store per lane, the slice's 1 KiB in whole lines
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hn), hx_rsrc, (unsigned)(c * 16 + 4 * g) * 4u,
-                                               (unsigned)(((l * 2 + (t & 1)) * P + ug) * 256) * 4u, AGENT_SCOPE);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        arrive_flush();
+        // the slice [sequence][UW units] goes out in 16-byte pieces, its 64 UW bytes in whole 128-byte
+        // lines by one store instruction
+        const unsigned slice = (unsigned)((l * 2 + (t & 1)) * H * ST + ug * UW * ST) * 4u;
+        if (UW == 16) {
+          const f32x4 hv4 = {hn[0], hn[UPL > 1 ? 1 : 0], hn[UPL > 2 ? 2 : 0], hn[UPL > 3 ? 3 : 0]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv4), hx_rsrc, (unsigned)(c * 16 + 4 * g) * 4u,
+                                                 slice, AGENT_SCOPE);
+        } else {
+          // a lane holds fewer than four units: regrouped through LDS (the wave's own accesses stay in order)
+#pragma unroll
+          for (int e = 0; e < UPL; ++e) pub[c * UW + g * UPL + e] = hn[e];
+          if (lane < 4 * UW)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ld4(pub + 4 * lane)), hx_rsrc,
+                                                   (unsigned)lane * 16u, slice, AGENT_SCOPE);
+        }
+        pend = l;
+        if (!(l == NL - 1 && NL > 1 && t < a.seq_len - 1)) arrive_flush();
         SP_MARK(1)  // store acknowledged
-        if (lane == 0)
-          __hip_atomic_fetch_add(cnt_tile + l * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (l < NL - 1) {
         if (l == NL - 2 && pending_top) {  // the layer above needs both: one wait, one round trip
@@ -1104,28 +1164,46 @@ static int rnn_prepare(const RnnModel* m) {
   return pf();
 }
 
-template <int KIND, int H, int NL>
+template <int KIND, int H, int NL, int UW>
 static int launch_split(const SArgs& a, int tiles, hipStream_t stream) {
-  hipLaunchKernelGGL((rnn_split_kernel<KIND, H, NL>), dim3((unsigned)(tiles * (H / 16))), dim3(256), 0,
+  hipLaunchKernelGGL((rnn_split_kernel<KIND, H, NL, UW>), dim3((unsigned)(tiles * (H / UW))), dim3(256), 0,
                      stream, a);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
+// uw: hidden units per workgroup (split_units())
 template <int KIND>
-static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, hipStream_t s) {
-#define CET_SPLIT_CASE(H_, NL_) \
-  if (m->H == H_ && m->layers == NL_) return launch_split<KIND, H_, NL_>(a, tiles, s);
+static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, int uw, hipStream_t s) {
+#define CET_SPLIT_CASE(H_, NL_)                                                          \
+  if (m->H == H_ && m->layers == NL_) {                                                  \
+    if (KIND != CET_RNN_TANH && uw == 4) return launch_split<KIND, H_, NL_, KIND == CET_RNN_TANH ? 16 : 4>(a, tiles, s); \
+    if (KIND != CET_RNN_TANH && uw == 8) return launch_split<KIND, H_, NL_, KIND == CET_RNN_TANH ? 16 : 8>(a, tiles, s); \
+    return launch_split<KIND, H_, NL_, 16>(a, tiles, s);                                 \
+  }
   CET_SPLIT_CASE(128, 1) CET_SPLIT_CASE(128, 2) CET_SPLIT_CASE(128, 3)
   CET_SPLIT_CASE(256, 1) CET_SPLIT_CASE(256, 2) CET_SPLIT_CASE(256, 3)
 #undef CET_SPLIT_CASE
   return CET_ERR_UNSUPPORTED;
 }
 
+// Hidden units per workgroup for a launch of `tiles` sequence tiles: as few as the CU count (and the
+// caller's workgroup limit) allows, so that a small batch spreads over the whole device; the tanh
+// cell has one row group and gains nothing below 16.
+static int split_units(const RnnModel* m, int tiles, int max_wg) {
+  if (m->kind == CET_RNN_TANH) return 16;
+  const long lim = m->cus < max_wg ? m->cus : max_wg;
+  for (int uw = 4; uw < 16; uw *= 2)
+    if ((long)tiles * (m->H / uw) <= lim) return uw;
+  return 16;
+}
+
 // Workgroups of the hidden-split kernel for a batch, and whether they are all resident at once.
 static int split_tiles(int B) { return (B + ST - 1) / ST; }
 static bool split_fits(const RnnModel* m, int B, int max_wg) {
   const long wg = (long)split_tiles(B) * (m->H / 16);
-  if ((size_t)split_tiles(B) * m->layers > SPLIT_CNT_SLOTS) return false;  // counters + failure flag
+  // counters (at most 16 per layer over the tiles of a launch that fits the CUs, whatever the split)
+  // + failure flag
+  if ((size_t)split_tiles(B) * m->layers > SPLIT_CNT_SLOTS) return false;
   return wg <= m->cus && wg <= max_wg;
 }
 
@@ -1141,7 +1219,7 @@ static RArgs tiled_args(const RnnModel* m, const float* x, float* out, int B, in
 // 256 floats): zeroes the counters, launches, and launches the batch-tiled kernel behind it on
 // condition of the failure flag. Allocates nothing.
 static int rollout_split(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
-                         float* scratch, hipStream_t stream) {
+                         float* scratch, int max_wg, hipStream_t stream) {
   SArgs a{};
   a.spin_limit = m->variant == 3 ? 0 : SPIN_LIMIT;
   for (int l = 0; l < 3; ++l) {
@@ -1154,18 +1232,19 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
   a.hx = scratch + SPLIT_CNT_FLOATS;
   CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
   const int tiles = split_tiles(B);
+  const int uw = split_units(m, tiles, max_wg);
 #ifdef CET_PROF
   static unsigned long long* sp_dev = nullptr;
-  const int sp_wg = tiles * (m->H / 16);
+  const int sp_wg = tiles * (m->H / uw);
   if (!sp_dev) CET_HIP(hipMalloc(&sp_dev, 1024 * SP_WORDS * sizeof(unsigned long long)));
   CET_HIP(hipMemsetAsync(sp_dev, 0, 1024 * SP_WORDS * sizeof(unsigned long long), stream));
   a.prof = sp_wg <= 1024 ? sp_dev : nullptr;
 #endif
   int rc;
   switch (m->kind) {
-    case CET_RNN_TANH: rc = launch_split_kind<CET_RNN_TANH>(m, a, tiles, stream); break;
-    case CET_RNN_GRU: rc = launch_split_kind<CET_RNN_GRU>(m, a, tiles, stream); break;
-    default: rc = launch_split_kind<CET_RNN_LSTM>(m, a, tiles, stream); break;
+    case CET_RNN_TANH: rc = launch_split_kind<CET_RNN_TANH>(m, a, tiles, uw, stream); break;
+    case CET_RNN_GRU: rc = launch_split_kind<CET_RNN_GRU>(m, a, tiles, uw, stream); break;
+    default: rc = launch_split_kind<CET_RNN_LSTM>(m, a, tiles, uw, stream); break;
   }
   if (rc != CET_OK) return rc;
 #ifdef CET_PROF
@@ -1236,7 +1315,7 @@ void rnn_select(RnnModel* m, int variant) { m->variant = variant; }
 int rnn_rollout_static(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                        hipStream_t stream) {
   if (!split_fits(m, B, SPLIT_MAX_WG) || m->layers > SPLIT_MAX_LAYERS) return CET_ERR_TOO_LARGE;
-  return rollout_split(m, x, out, B, seq_len, pred_len, m->static_scratch, stream);
+  return rollout_split(m, x, out, B, seq_len, pred_len, m->static_scratch, SPLIT_MAX_WG, stream);
 }
 
 // Sequences one launch of the hidden-split kernel takes on this handle's device (whole tiles).
@@ -1277,7 +1356,7 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
       rc = !split_fits(m, nb, m->cus)
                ? CET_ERR_TOO_LARGE
                : rollout_split(m, x + (size_t)b0 * seq_len * m->F, out + (size_t)b0 * pred_len * m->F, nb,
-                               seq_len, pred_len, pool.slot[slot].buf, stream);
+                               seq_len, pred_len, pool.slot[slot].buf, m->cus, stream);
     }
     // the slot is free again behind whatever was launched
     const hipError_t e = hipEventRecord(pool.slot[slot].done, stream);

@@ -2,9 +2,9 @@ import os, sys, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import channelestimationtransformer_amd as cet
 from channelestimationtransformer_amd import synth
-for name in ("GRU", "RNN"):
+for name in ("GRU", "LSTM"):
     m = getattr(cet, name)(16, 32, 256, 2).eval().select_kernel("split")
-    for B in (16, 256):
+    for B in (16, 64, 128, 256):
         noisy, _ = synth.channel_histories(B, seed=1)
         x = cet.LoadBatch(noisy[:, :25]).cuda()
         for _ in range(3):
