@@ -455,8 +455,8 @@ constexpr int ST = 16;        // sequences per workgroup
 // 512-byte block every poll and every arrival of the whole grid went to one memory channel), and in
 // the last word the grid's failure flag.
 constexpr int CNT_STRIDE = 32;                 // words between counters
-constexpr size_t SPLIT_CNT_SLOTS = 127;        // counters the header has room for
-constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 16 KiB
+constexpr size_t SPLIT_CNT_SLOTS = 255;        // counters the header has room for
+constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 32 KiB
 constexpr int SPIN_LIMIT = 1 << 20;  // polls of about a microsecond each: a second or two
 
 DEV f32x4 mfma16(float a, float b, f32x4 c) {
@@ -493,7 +493,7 @@ constexpr int SP_WORDS = 8;
 // batch of up to 64 sequences spreads over four times as many CUs. The launcher picks the
 // smallest UW whose grid fits the device.
 template <int KIND, int H, int NL, int UW>
-__global__ __launch_bounds__(256, 1) void rnn_split_kernel(const SArgs a) {
+__global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const SArgs a) {
   constexpr int G = Cell<KIND>::G, NACC = Cell<KIND>::NACC;
   constexpr bool LSTM = KIND == CET_RNN_LSTM, GRU = KIND == CET_RNN_GRU;
   constexpr int P = H / UW;            // workgroups per sequence tile
@@ -931,7 +931,11 @@ struct RnnModel {
   // exchange gives up at its first unanswered poll (tests: exercises the stand-by launch)
   int variant = 0;
   float* static_scratch = nullptr;  // device address of g_split_scratch on this handle's device
+  // workgroups of the hidden-split kernel that a CU holds at once, for 4, 8 and 16 hidden units per
+  // workgroup (registers and LDS decide; at most SPLIT_MAX_OCC are used)
+  int split_occ[3] = {1, 1, 1};
 };
+constexpr int SPLIT_MAX_OCC = 2;
 
 // Exchange buffers of the hidden-split kernel: SPLIT_SLOTS per GPU, shared by all handles on it,
 // allocated by the first rollout that needs one and kept until the process ends. A rollout claims
@@ -958,6 +962,7 @@ struct SplitPool {
 static SplitPool g_split_pool[SPLIT_MAX_DEVICES];
 
 static int rnn_prepare(const RnnModel* m);  // per-device kernel attributes, defined with the launchers
+static int rnn_split_occupancy(RnnModel* m);  // fills split_occ, defined with the launchers
 
 static int gates_of(int kind) { return kind == CET_RNN_TANH ? 1 : (kind == CET_RNN_GRU ? 3 : 4); }
 
@@ -1099,7 +1104,9 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     rnn_destroy(m);
     return hip_fail(e);
   }
-  if (const int rc = rnn_prepare(m)) {
+  int rc = rnn_prepare(m);
+  if (rc == CET_OK) rc = rnn_split_occupancy(m);
+  if (rc != CET_OK) {
     rnn_destroy(m);
     return rc;
   }
@@ -1171,40 +1178,83 @@ static int launch_split(const SArgs& a, int tiles, hipStream_t stream) {
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
-// uw: hidden units per workgroup (split_units())
+template <int KIND, int H, int NL, int UW>
+static int occupancy_split(int* occ) {
+  CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+      occ, reinterpret_cast<const void*>(&rnn_split_kernel<KIND, H, NL, UW>), 256, 0));
+  return CET_OK;
+}
+// uw: hidden units per workgroup (split_units()). occ != nullptr: no launch, the workgroups of that
+// instantiation a CU holds at once instead.
 template <int KIND>
-static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, int uw, hipStream_t s) {
+static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, int uw, hipStream_t s,
+                             int* occ = nullptr) {
+#define CET_SPLIT_DO(H_, NL_, UW_) \
+  return occ ? occupancy_split<KIND, H_, NL_, UW_>(occ) : launch_split<KIND, H_, NL_, UW_>(a, tiles, s)
 #define CET_SPLIT_CASE(H_, NL_)                                                          \
   if (m->H == H_ && m->layers == NL_) {                                                  \
-    if (KIND != CET_RNN_TANH && uw == 4) return launch_split<KIND, H_, NL_, KIND == CET_RNN_TANH ? 16 : 4>(a, tiles, s); \
-    if (KIND != CET_RNN_TANH && uw == 8) return launch_split<KIND, H_, NL_, KIND == CET_RNN_TANH ? 16 : 8>(a, tiles, s); \
-    return launch_split<KIND, H_, NL_, 16>(a, tiles, s);                                 \
+    if (KIND != CET_RNN_TANH && uw == 4) CET_SPLIT_DO(H_, NL_, (KIND == CET_RNN_TANH ? 16 : 4)); \
+    if (KIND != CET_RNN_TANH && uw == 8) CET_SPLIT_DO(H_, NL_, (KIND == CET_RNN_TANH ? 16 : 8)); \
+    CET_SPLIT_DO(H_, NL_, 16);                                                           \
   }
   CET_SPLIT_CASE(128, 1) CET_SPLIT_CASE(128, 2) CET_SPLIT_CASE(128, 3)
   CET_SPLIT_CASE(256, 1) CET_SPLIT_CASE(256, 2) CET_SPLIT_CASE(256, 3)
 #undef CET_SPLIT_CASE
+#undef CET_SPLIT_DO
   return CET_ERR_UNSUPPORTED;
 }
-
-// Hidden units per workgroup for a launch of `tiles` sequence tiles: as few as the CU count (and the
-// caller's workgroup limit) allows, so that a small batch spreads over the whole device; the tanh
-// cell has one row group and gains nothing below 16.
-static int split_units(const RnnModel* m, int tiles, int max_wg) {
-  if (m->kind == CET_RNN_TANH) return 16;
-  const long lim = m->cus < max_wg ? m->cus : max_wg;
-  for (int uw = 4; uw < 16; uw *= 2)
-    if ((long)tiles * (m->H / uw) <= lim) return uw;
-  return 16;
+static int split_kind_dispatch(const RnnModel* m, const SArgs& a, int tiles, int uw, hipStream_t s, int* occ) {
+  switch (m->kind) {
+    case CET_RNN_TANH: return launch_split_kind<CET_RNN_TANH>(m, a, tiles, uw, s, occ);
+    case CET_RNN_GRU: return launch_split_kind<CET_RNN_GRU>(m, a, tiles, uw, s, occ);
+    default: return launch_split_kind<CET_RNN_LSTM>(m, a, tiles, uw, s, occ);
+  }
 }
 
-// Workgroups of the hidden-split kernel for a batch, and whether they are all resident at once.
+static int rnn_split_occupancy(RnnModel* m) {
+  const SArgs none{};
+  for (int k = 0; k < 3; ++k) {
+    int occ = 1;
+    if (const int rc = split_kind_dispatch(m, none, 0, 4 << k, nullptr, &occ)) return rc;
+    m->split_occ[k] = occ < 1 ? 1 : occ;
+  }
+  return CET_OK;
+}
+
+// Workgroups of a launch with `uw` hidden units per workgroup that are resident at once, with one
+// workgroup per CU or with as many as fit (at most SPLIT_MAX_OCC).
+static long split_capacity(const RnnModel* m, int uw, bool shared_cu) {
+  const int occ = m->split_occ[uw == 4 ? 0 : (uw == 8 ? 1 : 2)];
+  return (long)m->cus * (shared_cu ? (occ < SPLIT_MAX_OCC ? occ : SPLIT_MAX_OCC) : 1);
+}
+
+// Hidden units per workgroup for a launch of `tiles` sequence tiles (0: the tiles do not fit one
+// launch). With a CU to itself a workgroup is fastest, so first the finest split that fits one
+// workgroup per CU (a small batch spreads over the whole device; the tanh cell has one row group
+// and gains nothing below 16); else the coarsest split whose workgroups fit two to a CU: they run
+// in step and share the MFMA pipes, so two to a CU only pay where the alternative is a second launch
+// (256 sequences of 256 hidden units, two layers: 16 units and one per CU 0.22 / 0.24 ms for GRU /
+// LSTM, 8 units and two per CU 0.25 / 0.25 ms; the tanh cell fits two to a CU at 16 units: 512
+// sequences in 0.18 ms instead of 0.30).
+static int split_units(const RnnModel* m, int tiles) {
+  for (int uw = m->kind == CET_RNN_TANH ? 16 : 4; uw <= 16; uw *= 2)
+    if ((long)tiles * (m->H / uw) <= split_capacity(m, uw, false)) return uw;
+  for (int uw = 16; uw >= (m->kind == CET_RNN_TANH ? 16 : 4); uw /= 2)
+    if ((long)tiles * (m->H / uw) <= split_capacity(m, uw, true)) return uw;
+  return 0;
+}
+
+// Whether the hidden-split kernel takes a batch in one launch: all its workgroups resident at once
+// (under some split of the hidden units), counters for its tiles, and an exchange area of at most
+// max_wg16 * layers * 2 * 256 floats (a tile's area is that of H / 16 workgroups of 16 units).
 static int split_tiles(int B) { return (B + ST - 1) / ST; }
-static bool split_fits(const RnnModel* m, int B, int max_wg) {
-  const long wg = (long)split_tiles(B) * (m->H / 16);
-  // counters (at most 16 per layer over the tiles of a launch that fits the CUs, whatever the split)
-  // + failure flag
-  if ((size_t)split_tiles(B) * m->layers > SPLIT_CNT_SLOTS) return false;
-  return wg <= m->cus && wg <= max_wg;
+static bool split_fits(const RnnModel* m, int B, long max_wg16) {
+  const int tiles = split_tiles(B);
+  if ((long)tiles * (m->H / 16) > max_wg16) return false;
+  const int uw = split_units(m, tiles);
+  if (!uw) return false;
+  const int ns = m->H / uw > 16 ? m->H / uw / 16 : 1;
+  return (size_t)tiles * m->layers * ns <= SPLIT_CNT_SLOTS;  // the last slot is the failure flag
 }
 
 static RArgs tiled_args(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len) {
@@ -1219,7 +1269,7 @@ static RArgs tiled_args(const RnnModel* m, const float* x, float* out, int B, in
 // 256 floats): zeroes the counters, launches, and launches the batch-tiled kernel behind it on
 // condition of the failure flag. Allocates nothing.
 static int rollout_split(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
-                         float* scratch, int max_wg, hipStream_t stream) {
+                         float* scratch, hipStream_t stream) {
   SArgs a{};
   a.spin_limit = m->variant == 3 ? 0 : SPIN_LIMIT;
   for (int l = 0; l < 3; ++l) {
@@ -1232,7 +1282,8 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
   a.hx = scratch + SPLIT_CNT_FLOATS;
   CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
   const int tiles = split_tiles(B);
-  const int uw = split_units(m, tiles, max_wg);
+  const int uw = split_units(m, tiles);
+  if (!uw) return CET_ERR_TOO_LARGE;
 #ifdef CET_PROF
   static unsigned long long* sp_dev = nullptr;
   const int sp_wg = tiles * (m->H / uw);
@@ -1240,12 +1291,7 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
   CET_HIP(hipMemsetAsync(sp_dev, 0, 1024 * SP_WORDS * sizeof(unsigned long long), stream));
   a.prof = sp_wg <= 1024 ? sp_dev : nullptr;
 #endif
-  int rc;
-  switch (m->kind) {
-    case CET_RNN_TANH: rc = launch_split_kind<CET_RNN_TANH>(m, a, tiles, uw, stream); break;
-    case CET_RNN_GRU: rc = launch_split_kind<CET_RNN_GRU>(m, a, tiles, uw, stream); break;
-    default: rc = launch_split_kind<CET_RNN_LSTM>(m, a, tiles, uw, stream); break;
-  }
+  const int rc = split_kind_dispatch(m, a, tiles, uw, stream, nullptr);
   if (rc != CET_OK) return rc;
 #ifdef CET_PROF
   if (a.prof && getenv("CET_SPLIT_PROF")) {
@@ -1277,7 +1323,7 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
 // Claims an exchange buffer of this device's pool for launches on `stream` (see SplitPool). The
 // caller holds pool.mu and keeps it until it has recorded the slot's event behind its launches.
 static int split_claim(const RnnModel* m, SplitPool& pool, hipStream_t stream, int* slot_out) {
-  const size_t need = (SPLIT_CNT_FLOATS + (size_t)m->cus * SPLIT_MAX_LAYERS * 2 * 256) * sizeof(float);
+  const size_t need = (SPLIT_CNT_FLOATS + (size_t)SPLIT_MAX_OCC * m->cus * SPLIT_MAX_LAYERS * 2 * 256) * sizeof(float);
   if (pool.slot_bytes < need) {  // first use on this device (the CU count of a device is fixed)
     for (int i = 0; i < SPLIT_SLOTS; ++i) {
       SplitSlot& sl = pool.slot[i];
@@ -1315,24 +1361,32 @@ void rnn_select(RnnModel* m, int variant) { m->variant = variant; }
 int rnn_rollout_static(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                        hipStream_t stream) {
   if (!split_fits(m, B, SPLIT_MAX_WG) || m->layers > SPLIT_MAX_LAYERS) return CET_ERR_TOO_LARGE;
-  return rollout_split(m, x, out, B, seq_len, pred_len, m->static_scratch, SPLIT_MAX_WG, stream);
+  return rollout_split(m, x, out, B, seq_len, pred_len, m->static_scratch, stream);
 }
 
 // Sequences one launch of the hidden-split kernel takes on this handle's device (whole tiles).
-static int split_chunk(const RnnModel* m) { return (m->cus / (m->H / 16)) * ST; }
+static int split_chunk(const RnnModel* m) {
+  long tiles = 0;
+  for (int uw = m->kind == CET_RNN_TANH ? 16 : 4; uw <= 16; uw *= 2) {
+    const long t = split_capacity(m, uw, true) / (m->H / uw);
+    if (t > tiles) tiles = t;
+  }
+  return (int)tiles * ST;
+}
 
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream) {
   // Small and medium batches: hidden units split over workgroups (a batch-tiled rollout of 64
   // sequences keeps 2 of the CUs busy for as long as one of 8192 keeps all of them busy). One
-  // launch takes as many sequences as its workgroups fit the CUs (256 at 256 hidden units) and
-  // needs the same time for any number of them; larger batches go through it in chunks, one launch
-  // after the other on the stream, for as long as that beats the batch-tiled kernel, whose time
-  // is the same from 32 to 8192 sequences (measured per launch / per batch-tiled rollout, 2 layers
-  // of 256: GRU 0.26 / 2.0 ms, LSTM 0.26 / 2.7 ms, tanh 0.16 / 0.73 ms).
+  // launch takes as many sequences as its workgroups are resident at once (256 at 256 hidden
+  // units for GRU and LSTM, 512 for the tanh cell, whose workgroups fit two to a CU); larger
+  // batches go through it in chunks, one launch after the other on the stream, for as long as that
+  // beats the batch-tiled kernel, whose time is the same from 32 to 8192 sequences (measured per
+  // full launch / per batch-tiled rollout, 2 layers of 256: GRU 0.22 / 2.0 ms, LSTM 0.24 / 2.6 ms,
+  // tanh 0.18 / 0.70 ms).
   const int chunk = split_chunk(m);
   const int n_chunks = chunk > 0 ? (B + chunk - 1) / chunk : 0;
-  const int max_chunks = m->kind == CET_RNN_TANH ? 4 : (m->kind == CET_RNN_GRU ? 7 : 9);
+  const int max_chunks = m->kind == CET_RNN_TANH ? 3 : (m->kind == CET_RNN_GRU ? 8 : 10);
   bool split = chunk > 0 && B > 0 && (m->variant >= 2 || (m->variant == 0 && n_chunks <= max_chunks));
   if (split) {
     // Under stream capture the launches would be replayed later, outside the pool's bookkeeping:
@@ -1353,10 +1407,10 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
     int rc = CET_OK;
     for (int b0 = 0; b0 < B && rc == CET_OK; b0 += chunk) {
       const int nb = B - b0 < chunk ? B - b0 : chunk;
-      rc = !split_fits(m, nb, m->cus)
+      rc = !split_fits(m, nb, (long)SPLIT_MAX_OCC * m->cus)
                ? CET_ERR_TOO_LARGE
                : rollout_split(m, x + (size_t)b0 * seq_len * m->F, out + (size_t)b0 * pred_len * m->F, nb,
-                               seq_len, pred_len, pool.slot[slot].buf, m->cus, stream);
+                               seq_len, pred_len, pool.slot[slot].buf, stream);
     }
     // the slot is free again behind whatever was launched
     const hipError_t e = hipEventRecord(pool.slot[slot].done, stream);

@@ -153,11 +153,13 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
 
 /* Pins the kernel of later rollouts of this handle (tests and timing): 0 by batch size, 1 the
  * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
- * kernel for small batches (16 sequences and 16 hidden units per workgroup, hidden states
- * exchanged through a buffer of the library once per layer and step; one launch takes as many
- * sequences as ceil(B / 16) * hidden / 16 workgroups fit the device's CU count, larger batches go
- * through it in chunks, launch after launch - which choice 0 does for as long as it beats the
- * batch-tiled kernel, a few chunks), 3 the same with an exchange that gives up at its first
+ * kernel for small batches (16 sequences and 4, 8 or 16 hidden units per workgroup - as few as
+ * keeps the launch's workgroups resident at once, so that a small batch spreads over the whole
+ * device -, hidden states exchanged through a buffer of the library once per layer and step; one
+ * launch takes as many sequences as ceil(B / 16) * hidden / 16 workgroups fit the device's CU
+ * count, twice that where two such workgroups fit a CU; larger batches go through it in chunks,
+ * launch after launch - which choice 0 does for as long as it beats the batch-tiled kernel, a
+ * few chunks), 3 the same with an exchange that gives up at its first
  * unanswered poll (tests: every chunk is then computed by the stand-by launch described next).
  * Rollouts on the hidden-split kernel may overlap freely, on any streams and handles and from any
  * host threads: each call claims one of four exchange buffers per GPU (a call that finds all four in flight on other
@@ -174,8 +176,9 @@ int cet_rnn_select(cet_handle h, int kernel);
  * tight serving loops, harnesses that forbid hipMalloc): always the hidden-split kernel, with its
  * exchange buffer in a static device array of the library (1.5 MiB per GPU) instead of the buffer
  * cet_rnn_rollout allocates on its first small batch. Calls hipMalloc / hipFree on no path.
- * Limit: ceil(B / 16) * hidden / 16 <= min(256, CU count) (B <= 256 at hidden 256, B <= 512 at
- * hidden 128), else CET_ERR_TOO_LARGE. All calls on one GPU share the array: calls that overlap in
+ * Limit: ceil(B / 16) * hidden / 16 <= 256 (B <= 256 at hidden 256, B <= 512 at hidden 128) and
+ * the launch's workgroups resident at once (CU count, twice that where two fit a CU), else
+ * CET_ERR_TOO_LARGE. All calls on one GPU share the array: calls that overlap in
  * time on one GPU (other streams, other handles) race (cet_rnn_rollout has no such limit). The
  * stand-by launch of the batch-tiled kernel follows here too. No counterpart in the reference. */
 int cet_rnn_rollout_static(cet_handle h, const float* x, float* out, int B, int seq_len,
