@@ -492,8 +492,11 @@ constexpr int SP_WORDS = 8;
 // issues a quarter of the MFMAs per layer step (128 instead of 384 / 512 at 256 hidden units) and a
 // batch of up to 64 sequences spreads over four times as many CUs. The launcher picks the
 // smallest UW whose grid fits the device.
-template <int KIND, int H, int NL, int UW>
-__global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const SArgs a) {
+// TPW: sequence tiles per workgroup (1 or 2). A workgroup's weights serve any tile, so with two it
+// takes a layer step of the first, then of the second, and only then waits for the first one's
+// exchange, which the second one's matrix work has covered meanwhile.
+template <int KIND, int H, int NL, int UW, int TPW>
+__global__ __launch_bounds__(256, (UW < 16 && TPW == 1) ? 2 : 1) void rnn_split_kernel(const SArgs a) {
   constexpr int G = Cell<KIND>::G, NACC = Cell<KIND>::NACC;
   constexpr bool LSTM = KIND == CET_RNN_LSTM, GRU = KIND == CET_RNN_GRU;
   constexpr int P = H / UW;            // workgroups per sequence tile
@@ -515,18 +518,18 @@ __global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const S
   constexpr int JH = (2 * HB + 3) / 4;   // blocks of a higher layer per wave
   static_assert(UW == 4 || UW == 8 || UW == 16, "units per workgroup");
 
-  __shared__ __attribute__((aligned(16))) float xcur[ST * XS];   // this step's input features (layer-0 input)
-  __shared__ __attribute__((aligned(16))) float hfull[NL][ST * HS];
-  __shared__ __attribute__((aligned(16))) float part[4][NA > 2 ? NA : 2][256];
-  __shared__ __attribute__((aligned(16))) float pub[ST * UW];    // the own slice on its way out (UW < 16)
+  __shared__ __attribute__((aligned(16))) float xcur[TPW][ST * XS];   // this step's input features (layer-0 input)
+  __shared__ __attribute__((aligned(16))) float hfull[TPW][NL][ST * HS];
+  __shared__ __attribute__((aligned(16))) float part[TPW][4][NA > 2 ? NA : 2][256];
+  __shared__ __attribute__((aligned(16))) float pub[ST * UW];    // a slice on its way out (UW < 16)
   __shared__ int dead;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x / P, ug = blockIdx.x % P;
-  const int b0 = tile * ST;
-  const int bc = b0 + c < a.B ? b0 + c : a.B - 1;  // tail tile: replay the last sequence
+  // workgroup (tg, ug) takes tiles tg TPW + ts, ts < TPW, as far as the batch has them
+  const int tg = blockIdx.x / P, ug = blockIdx.x % P;
+  const int n_tiles = (a.B + ST - 1) / ST;
 
   // ---- this wave's weights, in registers for the whole rollout --------------------------------
   // Block b of a layer covers k = 16 b .. 16 b + 15 of [input ; hidden]; wave w owns blocks
@@ -598,30 +601,39 @@ __global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const S
       }
   }
 
-  for (int i = tid; i < NL * ST * HS; i += 256) (&hfull[0][0])[i] = 0.f;
-  for (int i = tid; i < ST * XS; i += 256) xcur[i] = 0.f;
+  for (int i = tid; i < TPW * NL * ST * HS; i += 256) (&hfull[0][0][0])[i] = 0.f;
+  for (int i = tid; i < TPW * ST * XS; i += 256) (&xcur[0][0])[i] = 0.f;
   if (tid == 0) dead = 0;
-  float hown[NL][UPL], cown[NL][UPL];  // wave 0: own slice of h (and c), units g UPL + e of sequence c
+  // wave 0: own slices of h (and c), units g UPL + e of sequence c of tile slot ts
+  float hown[TPW][NL][UPL], cown[TPW][NL][UPL];
 #pragma unroll
-  for (int l = 0; l < NL; ++l)
+  for (int ts = 0; ts < TPW; ++ts)
 #pragma unroll
-    for (int e = 0; e < UPL; ++e) hown[l][e] = cown[l][e] = 0.f;
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int e = 0; e < UPL; ++e) hown[ts][l][e] = cown[ts][l][e] = 0.f;
   __syncthreads();
 
-  // The tile's exchange area [layer][parity][unit group][sequence][UW units] through a buffer
+  // A tile's exchange area [layer][parity][unit group][sequence][UW units] through a buffer
   // descriptor: 16-byte agent-scope (sc1, write-through / L1-bypassing) stores and loads, a quarter
   // of the instructions of 4-byte ones and, for the stores, a sixth of their time per byte.
-  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      a.hx + (size_t)tile * NL * 2 * H * ST, 0, NL * 2 * H * ST * 4, 0x00020000);
   constexpr int AGENT_SCOPE = 16;  // sc1
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  unsigned* const cnt_tile = a.cnt + (size_t)tile * NL * NS * CNT_STRIDE;  // [layer][shard]
+  __amdgpu_buffer_rsrc_t hx_rsrc[TPW];
+  unsigned* cnt_tile[TPW];  // [layer][shard]
+  int b0[TPW];
+  bool live[TPW];           // the batch has this tile
+#pragma unroll
+  for (int ts = 0; ts < TPW; ++ts) {
+    const int tile = tg * TPW + ts;
+    live[ts] = tile < n_tiles;
+    b0[ts] = tile * ST;
+    hx_rsrc[ts] = __builtin_amdgcn_make_buffer_rsrc(a.hx + (size_t)tile * NL * 2 * H * ST, 0,
+                                                    live[ts] ? NL * 2 * H * ST * 4 : 0, 0x00020000);
+    cnt_tile[ts] = a.cnt + (size_t)tile * NL * NS * CNT_STRIDE;
+  }
   unsigned* const fail = a.cnt + (SPLIT_CNT_FLOATS - 1);  // set by any workgroup whose wait ran out
 
-  // Waits until every workgroup of the tile has published layer l of step t, then copies the
-  // layer's full hidden state into hfull[l].
-  // With l2 >= 0 the same for layer l2 of step t2 in the same round trip (the top layer's state of
-  // the step before, whose wait was put off until its first use).
 #ifdef CET_PROF
   unsigned long long sp[SP_WORDS] = {};
   unsigned long long sp_t = SP_NOW();
@@ -629,30 +641,48 @@ __global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const S
 #else
 #define SP_MARK(i)
 #endif
-  // The arrival at a layer's counter follows the acknowledgement of the slice's stores. For the top
-  // layer of a step whose prediction is not needed, nobody waits for that arrival before the next
-  // step's first layer has been computed, so it is put off until then (wave 0; `pend`: the layer)
-  // and the wait for the acknowledgement costs nothing.
-  int pend = -1;
-  auto arrive_flush = [&]() {
-    if (wave == 0 && pend >= 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_fetch_add(cnt_tile + (pend * NS + ug % NS) * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pend = -1;
+  // The arrival at a layer's counter follows the acknowledgement of the slice's stores. Waiting for
+  // that right behind the stores would hold wave 0 for half a microsecond, so the arrival is put
+  // off (pend[ts]: the layer, wave 0): to the middle of the next matrix product, where the
+  // acknowledgement has long come, at the latest to the next publication or to the fetch that needs
+  // it. For the top layer of a step whose prediction is not needed nobody waits before then.
+  int pend[TPW];
+#pragma unroll
+  for (int ts = 0; ts < TPW; ++ts) pend[ts] = -1;
+  auto arrive_flush = [&](const int only) __attribute__((always_inline)) {  // only: a tile slot, or -1 for all
+    if (wave == 0) {
+      bool any = false;
+#pragma unroll
+      for (int ts = 0; ts < TPW; ++ts) any = any || ((only < 0 || only == ts) && pend[ts] >= 0);
+      if (any) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ts = 0; ts < TPW; ++ts)
+          if ((only < 0 || only == ts) && pend[ts] >= 0) {
+            if (lane == 0)
+              __hip_atomic_fetch_add(cnt_tile[ts] + (pend[ts] * NS + ug % NS) * CNT_STRIDE, 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+            pend[ts] = -1;
+          }
+      }
     }
   };
-  auto fetch = [&](int l, int t, int l2 = -1, int t2 = 0) {
-    arrive_flush();
+  // Waits until every workgroup of tile slot ts has published layer l of step t, then copies the
+  // layer's full hidden state into hfull[ts][l].
+  // With l2 >= 0 the same for layer l2 of step t2 in the same round trip (the top layer's state of
+  // the step before, whose wait was put off until its first use).
+  auto fetch = [&](const int ts, const int l, const int t, const int l2 = -1, const int t2 = 0)
+                   __attribute__((always_inline)) {
+    arrive_flush(ts);  // the own arrival first: the tile's other workgroups wait for it as this one for theirs
     SP_MARK(2)  // publish -> fetch entry
     if (wave == 0 && !dead) {  // lane s < NS polls shard s; the wave leaves when every shard has arrived
       const unsigned target = (unsigned)(P / NS) * (unsigned)(t + 1), target2 = (unsigned)(P / NS) * (unsigned)(t2 + 1);
       const int sh = lane < NS ? lane : 0;
       int spins = 0;
       for (;;) {
-        bool ok = __hip_atomic_load(cnt_tile + (l * NS + sh) * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        bool ok = __hip_atomic_load(cnt_tile[ts] + (l * NS + sh) * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
         if (l2 >= 0)
-          ok = ok && __hip_atomic_load(cnt_tile + (l2 * NS + sh) * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target2;
+          ok = ok && __hip_atomic_load(cnt_tile[ts] + (l2 * NS + sh) * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target2;
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > a.spin_limit) {
@@ -675,12 +705,14 @@ __global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const S
     u32x4 v[NPC], v2[NPC];  // all loads of the round in flight together: one memory round trip
 #pragma unroll
     for (int r = 0; r < NPC; ++r)
-      v[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, voff + (unsigned)(r * 4 * 256 * 4), so, AGENT_SCOPE);
+      v[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc[ts], voff + (unsigned)(r * 4 * 256 * 4), so, AGENT_SCOPE);
     if (l2 >= 0) {
 #pragma unroll
       for (int r = 0; r < NPC; ++r)
-        v2[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, voff + (unsigned)(r * 4 * 256 * 4), so2, AGENT_SCOPE);
+        v2[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc[ts], voff + (unsigned)(r * 4 * 256 * 4), so2, AGENT_SCOPE);
     }
+    // another slot's arrival that is still pending: its acknowledgement comes with these loads
+    arrive_flush(-1);
     int at[NPC];
 #pragma unroll
     for (int r = 0; r < NPC; ++r) {
@@ -688,10 +720,10 @@ __global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const S
       at[r] = (q / UPL) * HS + UW * (p / (4 * UW)) + 4 * (q % UPL);
     }
 #pragma unroll
-    for (int r = 0; r < NPC; ++r) st4(&hfull[l][at[r]], __builtin_bit_cast(f32x4, v[r]));
+    for (int r = 0; r < NPC; ++r) st4(&hfull[ts][l][at[r]], __builtin_bit_cast(f32x4, v[r]));
     if (l2 >= 0) {
 #pragma unroll
-      for (int r = 0; r < NPC; ++r) st4(&hfull[l2][at[r]], __builtin_bit_cast(f32x4, v2[r]));
+      for (int r = 0; r < NPC; ++r) st4(&hfull[ts][l2][at[r]], __builtin_bit_cast(f32x4, v2[r]));
     }
     __syncthreads();
     SP_MARK(4)  // loads + LDS copy + barrier
@@ -701,188 +733,211 @@ __global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const S
   // FP floats: two 16-byte pieces per lane), so their memory latency is off the step's critical path.
   constexpr int XPL = ST * (FP / 4) / 64;
   const int f4n = a.F / 4;  // 16-byte pieces per row
-  f32x4 xpre[XPL];
-  auto request_x = [&](int t) {
+  f32x4 xpre[TPW][XPL];
+  auto request_x = [&](const int ts, const int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < XPL; ++r) {
       const int q = lane + 64 * r;
       if (q < ST * f4n) {
         const int sq = q / f4n, f4 = q % f4n;
-        const int bs = b0 + sq < a.B ? b0 + sq : a.B - 1;
-        xpre[r] = ld4(a.x + ((size_t)bs * a.seq_len + t) * a.F + 4 * f4);
+        const int bs = b0[ts] + sq < a.B ? b0[ts] + sq : a.B - 1;  // tail tile: replay the last sequence
+        xpre[ts][r] = ld4(a.x + ((size_t)bs * a.seq_len + t) * a.F + 4 * f4);
       }
     }
   };
-  if (wave == 0) request_x(0);
+  if (wave == 0) {
+#pragma unroll
+    for (int ts = 0; ts < TPW; ++ts)
+      if (live[ts]) request_x(ts, 0);
+  }
 
   const int n_steps = a.seq_len + a.pred_len - 1;
-  bool pending_top = false;
+  bool pending_top[TPW];
+#pragma unroll
+  for (int ts = 0; ts < TPW; ++ts) pending_top[ts] = false;
   for (int t = 0; t < n_steps; ++t) {
     // ---- input features of a teacher-forced step, wave 0 (a closed-loop step finds the decoder's
     // output of the step before in xcur) -------------------------------------------------------
     if (wave == 0 && t < a.seq_len) {
 #pragma unroll
-      for (int r = 0; r < XPL; ++r) {
-        const int q = lane + 64 * r;
-        if (q < ST * f4n) st4(xcur + (q / f4n) * XS + 4 * (q % f4n), xpre[r]);
-      }
-      if (t + 1 < a.seq_len) request_x(t + 1);
+      for (int ts = 0; ts < TPW; ++ts)
+        if (live[ts]) {
+#pragma unroll
+          for (int r = 0; r < XPL; ++r) {
+            const int q = lane + 64 * r;
+            if (q < ST * f4n) st4(xcur[ts] + (q / f4n) * XS + 4 * (q % f4n), xpre[ts][r]);
+          }
+          if (t + 1 < a.seq_len) request_x(ts, t + 1);
+        }
     }
     __syncthreads();
 
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-      if (l == NL - 1 && pending_top) {  // only when no lower layer's fetch took it along (NL == 1)
-        fetch(NL - 1, t - 1);
-        pending_top = false;
-      }
-      // ---- partial gate sums over this wave's k blocks ---------------------------------------------
-      f32x4 acc[NA];
 #pragma unroll
-      for (int q = 0; q < NA; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // one k block of 16: B operand bv, weights wt[row tile], is_x: the block belongs to the layer's
-      // input; the row tiles take turns so that consecutive MFMAs do not wait for each other
-      auto block = [&](const f32x4 bv, const f32x4 (&wt)[NTW], const bool is_x) {
+      for (int ts = 0; ts < TPW; ++ts) {
+        if (!live[ts]) continue;
+        if (l == NL - 1 && pending_top[ts]) {  // only when no lower layer's fetch took it along (NL == 1)
+          fetch(ts, NL - 1, t - 1);
+          pending_top[ts] = false;
+        }
+        // ---- partial gate sums over this wave's k blocks -------------------------------------------
+        f32x4 acc[NA];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < NA; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // one k block of 16: B operand bv, weights wt[row tile], is_x: the block belongs to the layer's
+        // input; the row tiles take turns so that consecutive MFMAs do not wait for each other
+        auto block = [&](const f32x4 bv, const f32x4 (&wt)[NTW], const bool is_x) __attribute__((always_inline)) {
 #pragma unroll
-          for (int m = 0; m < NTW; ++m) {
-            if (SHARE_N && m == 2) {  // n gate: W_in x apart from W_hn h
-              if (is_x) acc[2] = mfma16(wt[m][i], bv[i], acc[2]);
-              else acc[NA - 1] = mfma16(wt[m][i], bv[i], acc[NA - 1]);
-            } else {
-              acc[m] = mfma16(wt[m][i], bv[i], acc[m]);
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < NTW; ++m) {
+              if (SHARE_N && m == 2) {  // n gate: W_in x apart from W_hn h
+                if (is_x) acc[2] = mfma16(wt[m][i], bv[i], acc[2]);
+                else acc[NA - 1] = mfma16(wt[m][i], bv[i], acc[NA - 1]);
+              } else {
+                acc[m] = mfma16(wt[m][i], bv[i], acc[m]);
+              }
             }
-          }
-      };
-      if (l == 0) {
+        };
+        if (l == 0) {
 #pragma unroll
-        for (int j = 0; j < JX; ++j) {
-          const int b = 4 * j + wave;
-          if (b < XB + HB) {
-            const bool is_x = b < XB;
-            block(is_x ? ld4(xcur + c * XS + 16 * b + 4 * g) : ld4(hfull[0] + c * HS + 16 * (b - XB) + 4 * g),
-                  w0[j], is_x);
+          for (int j = 0; j < JX; ++j) {
+            const int b = 4 * j + wave;
+            if (b < XB + HB) {
+              const bool is_x = b < XB;
+              block(is_x ? ld4(xcur[ts] + c * XS + 16 * b + 4 * g) : ld4(hfull[ts][0] + c * HS + 16 * (b - XB) + 4 * g),
+                    w0[j], is_x);
+            }
+            if (j == JX / 2) arrive_flush(-1);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < JH; ++j) {
+            const int b = 4 * j + wave;
+            if (b < 2 * HB) {
+              const bool is_x = b < HB;
+              block(is_x ? ld4(hfull[ts][l - 1] + c * HS + 16 * b + 4 * g) : ld4(hfull[ts][l] + c * HS + 16 * (b - HB) + 4 * g),
+                    wh[l > 0 ? l - 1 : 0][j], is_x);
+            }
+            if (j == JH / 2) arrive_flush(-1);
           }
         }
-      } else {
 #pragma unroll
-        for (int j = 0; j < JH; ++j) {
-          const int b = 4 * j + wave;
-          if (b < 2 * HB) {
-            const bool is_x = b < HB;
-            block(is_x ? ld4(hfull[l - 1] + c * HS + 16 * b + 4 * g) : ld4(hfull[l] + c * HS + 16 * (b - HB) + 4 * g),
-                  wh[l > 0 ? l - 1 : 0][j], is_x);
+        for (int q = 0; q < NA; ++q) st4(&part[ts][wave][q][4 * lane], acc[q]);
+        __syncthreads();
+        // ---- cell update of the own UW x 16 slice and its publication, wave 0 ------------------------
+        if (wave == 0) {
+          // group q of this lane's units: rows q UW + g UPL + e of the gate product, i.e. row rr of tile
+          // m, which the lanes (rr / 4, c) of every wave hold in register rr % 4 of accumulator m
+          float s[NACC][UPL];
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) {
+            const int r0 = q * UW + g * UPL, m = r0 / 16, rr = r0 % 16;
+            const int off = 4 * (16 * (rr / 4) + c) + rr % 4;
+#pragma unroll
+            for (int e = 0; e < UPL; ++e)
+              s[q][e] = ((part[ts][0][m][off + e] + part[ts][1][m][off + e]) +
+                         (part[ts][2][m][off + e] + part[ts][3][m][off + e])) + bsum[l][q][e];
           }
-        }
-      }
+          float hn[UPL];
 #pragma unroll
-      for (int q = 0; q < NA; ++q) st4(&part[wave][q][4 * lane], acc[q]);
-      __syncthreads();
-      // ---- cell update of the own UW x 16 slice and its publication, wave 0 --------------------------
-      if (wave == 0) {
-        // group q of this lane's units: rows q UW + g UPL + e of the gate product, i.e. row rr of tile m,
-        // which the lanes (rr / 4, c) of every wave hold in register rr % 4 of accumulator m
-        float s[NACC][UPL];
-#pragma unroll
-        for (int q = 0; q < NACC; ++q) {
-          const int r0 = q * UW + g * UPL, m = r0 / 16, rr = r0 % 16;
-          const int off = 4 * (16 * (rr / 4) + c) + rr % 4;
-#pragma unroll
-          for (int e = 0; e < UPL; ++e)
-            s[q][e] = ((part[0][m][off + e] + part[1][m][off + e]) + (part[2][m][off + e] + part[3][m][off + e])) +
-                      bsum[l][q][e];
-        }
-        float hn[UPL];
-#pragma unroll
-        for (int e = 0; e < UPL; ++e) {
-          float hv;
-          if (KIND == CET_RNN_TANH) {
-            hv = tanhf_(s[0][e]);
-          } else if (GRU) {
-            const float rg = sigmoidf_(s[0][e]);
-            const float zg = sigmoidf_(s[1][e]);
-            const float ng = tanhf_(s[2][e] + rg * s[NACC - 1][e]);
-            hv = (1.0f - zg) * ng + zg * hown[l][e];
+          for (int e = 0; e < UPL; ++e) {
+            float hv;
+            if (KIND == CET_RNN_TANH) {
+              hv = tanhf_(s[0][e]);
+            } else if (GRU) {
+              const float rg = sigmoidf_(s[0][e]);
+              const float zg = sigmoidf_(s[1][e]);
+              const float ng = tanhf_(s[2][e] + rg * s[NACC - 1][e]);
+              hv = (1.0f - zg) * ng + zg * hown[ts][l][e];
+            } else {
+              const float ig = sigmoidf_(s[0][e]);
+              const float fg = sigmoidf_(s[1][e]);
+              const float gg = tanhf_(s[LSTM ? 2 : 0][e]);
+              const float og = sigmoidf_(s[LSTM ? 3 : 0][e]);
+              const float cv = __fadd_rn(__fmul_rn(fg, cown[ts][l][e]), __fmul_rn(ig, gg));
+              cown[ts][l][e] = cv;
+              hv = og * tanhf_(cv);
+            }
+            hn[e] = hv;
+            hown[ts][l][e] = hv;
+          }
+          SP_MARK(0)  // matrix work, partial sums, cell update
+          arrive_flush(-1);  // an arrival of the same counter must not overtake an earlier one's
+          // the slice [sequence][UW units] goes out in 16-byte pieces, its 64 UW bytes in whole 128-byte
+          // lines by one store instruction
+          const unsigned slice = (unsigned)((l * 2 + (t & 1)) * H * ST + ug * UW * ST) * 4u;
+          if (UW == 16) {
+            const f32x4 hv4 = {hn[0], hn[UPL > 1 ? 1 : 0], hn[UPL > 2 ? 2 : 0], hn[UPL > 3 ? 3 : 0]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv4), hx_rsrc[ts],
+                                                   (unsigned)(c * 16 + 4 * g) * 4u, slice, AGENT_SCOPE);
           } else {
-            const float ig = sigmoidf_(s[0][e]);
-            const float fg = sigmoidf_(s[1][e]);
-            const float gg = tanhf_(s[LSTM ? 2 : 0][e]);
-            const float og = sigmoidf_(s[LSTM ? 3 : 0][e]);
-            const float cv = __fadd_rn(__fmul_rn(fg, cown[l][e]), __fmul_rn(ig, gg));
-            cown[l][e] = cv;
-            hv = og * tanhf_(cv);
-          }
-          hn[e] = hv;
-          hown[l][e] = hv;
-        }
-        SP_MARK(0)  // matrix work, partial sums, cell update
-        arrive_flush();
-        // the slice [sequence][UW units] goes out in 16-byte pieces, its 64 UW bytes in whole 128-byte
-        // lines by one store instruction
-        const unsigned slice = (unsigned)((l * 2 + (t & 1)) * H * ST + ug * UW * ST) * 4u;
-        if (UW == 16) {
-          const f32x4 hv4 = {hn[0], hn[UPL > 1 ? 1 : 0], hn[UPL > 2 ? 2 : 0], hn[UPL > 3 ? 3 : 0]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hv4), hx_rsrc, (unsigned)(c * 16 + 4 * g) * 4u,
-                                                 slice, AGENT_SCOPE);
-        } else {
-          // a lane holds fewer than four units: regrouped through LDS (the wave's own accesses stay in order)
+            // a lane holds fewer than four units: regrouped through LDS (the wave's own accesses stay in order)
 #pragma unroll
-          for (int e = 0; e < UPL; ++e) pub[c * UW + g * UPL + e] = hn[e];
-          if (lane < 4 * UW)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ld4(pub + 4 * lane)), hx_rsrc,
-                                                   (unsigned)lane * 16u, slice, AGENT_SCOPE);
+            for (int e = 0; e < UPL; ++e) pub[c * UW + g * UPL + e] = hn[e];
+            if (lane < 4 * UW)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ld4(pub + 4 * lane)), hx_rsrc[ts],
+                                                     (unsigned)lane * 16u, slice, AGENT_SCOPE);
+          }
+          pend[ts] = l;
+          SP_MARK(1)  // slice stored
         }
-        pend = l;
-        if (!(l == NL - 1 && NL > 1 && t < a.seq_len - 1)) arrive_flush();
-        SP_MARK(1)  // store acknowledged
       }
-      if (l < NL - 1) {
-        if (l == NL - 2 && pending_top) {  // the layer above needs both: one wait, one round trip
-          fetch(l, t, NL - 1, t - 1);
-          pending_top = false;
+#pragma unroll
+      for (int ts = 0; ts < TPW; ++ts) {
+        if (!live[ts]) continue;
+        if (l < NL - 1) {
+          if (l == NL - 2 && pending_top[ts]) {  // the layer above needs both: one wait, one round trip
+            fetch(ts, l, t, NL - 1, t - 1);
+            pending_top[ts] = false;
+          } else {
+            fetch(ts, l, t);
+          }
         } else {
-          fetch(l, t);
+          pending_top[ts] = true;
         }
-      } else {
-        pending_top = true;
       }
     }
 
     // ---- decoder Linear on the new top hidden state: the prediction and the next input --------------
     if (t >= a.seq_len - 1) {
-      fetch(NL - 1, t);
-      pending_top = false;
-      f32x4 dacc[XB];
 #pragma unroll
-      for (int ft = 0; ft < XB; ++ft) dacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ts = 0; ts < TPW; ++ts) {
+        if (!live[ts]) continue;
+        fetch(ts, NL - 1, t);
+        pending_top[ts] = false;
+        f32x4 dacc[XB];
 #pragma unroll
-      for (int j = 0; j < HB / 4; ++j) {
-        const f32x4 bv = ld4(hfull[NL - 1] + c * HS + 16 * (4 * j + wave) + 4 * g);
+        for (int ft = 0; ft < XB; ++ft) dacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ft = 0; ft < XB; ++ft)
+        for (int j = 0; j < HB / 4; ++j) {
+          const f32x4 bv = ld4(hfull[ts][NL - 1] + c * HS + 16 * (4 * j + wave) + 4 * g);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dacc[ft] = mfma16(wd[ft][j][i], bv[i], dacc[ft]);
-      }
+          for (int ft = 0; ft < XB; ++ft)
 #pragma unroll
-      for (int ft = 0; ft < XB; ++ft) st4(&part[wave][ft][4 * lane], dacc[ft]);
-      __syncthreads();
-      if (wave == 0) {
-#pragma unroll
-        for (int ft = 0; ft < XB; ++ft) {
-          const f32x4 y = ((ld4(&part[0][ft][4 * lane]) + ld4(&part[1][ft][4 * lane])) +
-                           (ld4(&part[2][ft][4 * lane]) + ld4(&part[3][ft][4 * lane]))) + bd[ft];
-          st4(xcur + c * XS + 16 * ft + 4 * g, y);  // features 16 ft + 4 g + i of sequence c
-          const int f0 = 16 * ft + 4 * g;
-          if (ug == 0 && b0 + c < a.B && f0 < a.F)
-            st4(a.out + ((size_t)(b0 + c) * a.pred_len + (t - (a.seq_len - 1))) * a.F + f0, y);
+            for (int i = 0; i < 4; ++i) dacc[ft] = mfma16(wd[ft][j][i], bv[i], dacc[ft]);
         }
+#pragma unroll
+        for (int ft = 0; ft < XB; ++ft) st4(&part[ts][wave][ft][4 * lane], dacc[ft]);
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+          for (int ft = 0; ft < XB; ++ft) {
+            const f32x4 y = ((ld4(&part[ts][0][ft][4 * lane]) + ld4(&part[ts][1][ft][4 * lane])) +
+                             (ld4(&part[ts][2][ft][4 * lane]) + ld4(&part[ts][3][ft][4 * lane]))) + bd[ft];
+            st4(xcur[ts] + c * XS + 16 * ft + 4 * g, y);  // features 16 ft + 4 g + i of sequence c
+            const int f0 = 16 * ft + 4 * g;
+            if (ug == 0 && b0[ts] + c < a.B && f0 < a.F)
+              st4(a.out + ((size_t)(b0[ts] + c) * a.pred_len + (t - (a.seq_len - 1))) * a.F + f0, y);
+          }
+        }
+        // the next step's barrier orders these LDS writes before layer 0 reads them and the reads of
+        // `part` before it is written again
       }
-      // the next step's barrier orders these LDS writes before layer 0 reads them and the reads of
-      // `part` before it is written again
     }
   }
-  (void)bc;
+  arrive_flush(-1);  // nobody waits for it; the counters are simply complete
 #ifdef CET_PROF
   if (tid == 0 && a.prof) {
     SP_MARK(5)
@@ -895,10 +950,12 @@ __global__ __launch_bounds__(256, UW < 16 ? 2 : 1) void rnn_split_kernel(const S
   __syncthreads();
   if (ug == 0 && (dead || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
     const int per_seq = a.pred_len * a.F;
-    for (int i = tid; i < ST * per_seq; i += 256) {
-      const int sq = i / per_seq;
-      if (b0 + sq < a.B) a.out[(size_t)(b0 + sq) * per_seq + (i - sq * per_seq)] = __builtin_nanf("");
-    }
+#pragma unroll
+    for (int ts = 0; ts < TPW; ++ts)
+      for (int i = tid; i < ST * per_seq; i += 256) {
+        const int sq = i / per_seq;
+        if (b0[ts] + sq < a.B) a.out[(size_t)(b0[ts] + sq) * per_seq + (i - sq * per_seq)] = __builtin_nanf("");
+      }
   }
 }
 
@@ -932,8 +989,11 @@ struct RnnModel {
   int variant = 0;
   float* static_scratch = nullptr;  // device address of g_split_scratch on this handle's device
   // workgroups of the hidden-split kernel that a CU holds at once, for 4, 8 and 16 hidden units per
-  // workgroup (registers and LDS decide; at most SPLIT_MAX_OCC are used)
-  int split_occ[3] = {1, 1, 1};
+  // workgroup and for two tiles per workgroup (registers and LDS decide; at most SPLIT_MAX_OCC are used)
+  int split_occ[4] = {1, 1, 1, 1};
+  int split_spill[4] = {0, 0, 0, 0};  // scratch bytes per lane of the same instantiations
+  int split_chunk = 0;      // sequences one launch of the hidden-split kernel takes at most
+  int split_max_batch = 0;  // largest batch the automatic choice gives to the hidden-split kernel
 };
 constexpr int SPLIT_MAX_OCC = 2;
 
@@ -963,6 +1023,7 @@ static SplitPool g_split_pool[SPLIT_MAX_DEVICES];
 
 static int rnn_prepare(const RnnModel* m);  // per-device kernel attributes, defined with the launchers
 static int rnn_split_occupancy(RnnModel* m);  // fills split_occ, defined with the launchers
+static void rnn_split_limits(RnnModel* m);    // fills split_chunk from split_occ
 
 static int gates_of(int kind) { return kind == CET_RNN_TANH ? 1 : (kind == CET_RNN_GRU ? 3 : 4); }
 
@@ -1106,6 +1167,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   int rc = rnn_prepare(m);
   if (rc == CET_OK) rc = rnn_split_occupancy(m);
+  if (rc == CET_OK) rnn_split_limits(m);
   if (rc != CET_OK) {
     rnn_destroy(m);
     return rc;
@@ -1171,31 +1233,41 @@ static int rnn_prepare(const RnnModel* m) {
   return pf();
 }
 
-template <int KIND, int H, int NL, int UW>
+template <int KIND, int H, int NL, int UW, int TPW>
 static int launch_split(const SArgs& a, int tiles, hipStream_t stream) {
-  hipLaunchKernelGGL((rnn_split_kernel<KIND, H, NL, UW>), dim3((unsigned)(tiles * (H / UW))), dim3(256), 0,
-                     stream, a);
+  const unsigned groups = (unsigned)((tiles + TPW - 1) / TPW);
+  hipLaunchKernelGGL((rnn_split_kernel<KIND, H, NL, UW, TPW>), dim3(groups * (H / UW)), dim3(256), 0, stream, a);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
-template <int KIND, int H, int NL, int UW>
+// occ[0]: workgroups of the instantiation a CU holds at once; occ[1]: its scratch bytes per lane
+// (registers the compiler had to spill)
+template <int KIND, int H, int NL, int UW, int TPW>
 static int occupancy_split(int* occ) {
-  CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-      occ, reinterpret_cast<const void*>(&rnn_split_kernel<KIND, H, NL, UW>), 256, 0));
+  const void* fn = reinterpret_cast<const void*>(&rnn_split_kernel<KIND, H, NL, UW, TPW>);
+  CET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[0], fn, 256, 0));
+  hipFuncAttributes at{};
+  CET_HIP(hipFuncGetAttributes(&at, fn));
+  occ[1] = (int)at.localSizeBytes;
   return CET_OK;
 }
-// uw: hidden units per workgroup (split_units()). occ != nullptr: no launch, the workgroups of that
-// instantiation a CU holds at once instead.
+// How a launch of the hidden-split kernel is laid out: hidden units per workgroup (4, 8 or 16; 0: the
+// batch does not fit one launch) and sequence tiles per workgroup (2 only with 16 units).
+struct SplitPlan {
+  int uw, tpw;
+};
+// occ != nullptr: no launch, the residency and spill figures of that instantiation instead.
 template <int KIND>
-static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, int uw, hipStream_t s,
+static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, SplitPlan pl, hipStream_t s,
                              int* occ = nullptr) {
-#define CET_SPLIT_DO(H_, NL_, UW_) \
-  return occ ? occupancy_split<KIND, H_, NL_, UW_>(occ) : launch_split<KIND, H_, NL_, UW_>(a, tiles, s)
+#define CET_SPLIT_DO(H_, NL_, UW_, TPW_) \
+  return occ ? occupancy_split<KIND, H_, NL_, UW_, TPW_>(occ) : launch_split<KIND, H_, NL_, UW_, TPW_>(a, tiles, s)
 #define CET_SPLIT_CASE(H_, NL_)                                                          \
   if (m->H == H_ && m->layers == NL_) {                                                  \
-    if (KIND != CET_RNN_TANH && uw == 4) CET_SPLIT_DO(H_, NL_, (KIND == CET_RNN_TANH ? 16 : 4)); \
-    if (KIND != CET_RNN_TANH && uw == 8) CET_SPLIT_DO(H_, NL_, (KIND == CET_RNN_TANH ? 16 : 8)); \
-    CET_SPLIT_DO(H_, NL_, 16);                                                           \
+    if (KIND != CET_RNN_TANH && pl.uw == 4) CET_SPLIT_DO(H_, NL_, (KIND == CET_RNN_TANH ? 16 : 4), 1); \
+    if (KIND != CET_RNN_TANH && pl.uw == 8) CET_SPLIT_DO(H_, NL_, (KIND == CET_RNN_TANH ? 16 : 8), 1); \
+    if (pl.tpw == 2) CET_SPLIT_DO(H_, NL_, 16, 2);                                       \
+    CET_SPLIT_DO(H_, NL_, 16, 1);                                                        \
   }
   CET_SPLIT_CASE(128, 1) CET_SPLIT_CASE(128, 2) CET_SPLIT_CASE(128, 3)
   CET_SPLIT_CASE(256, 1) CET_SPLIT_CASE(256, 2) CET_SPLIT_CASE(256, 3)
@@ -1203,45 +1275,86 @@ static int launch_split_kind(const RnnModel* m, const SArgs& a, int tiles, int u
 #undef CET_SPLIT_DO
   return CET_ERR_UNSUPPORTED;
 }
-static int split_kind_dispatch(const RnnModel* m, const SArgs& a, int tiles, int uw, hipStream_t s, int* occ) {
+static int split_kind_dispatch(const RnnModel* m, const SArgs& a, int tiles, SplitPlan pl, hipStream_t s, int* occ) {
   switch (m->kind) {
-    case CET_RNN_TANH: return launch_split_kind<CET_RNN_TANH>(m, a, tiles, uw, s, occ);
-    case CET_RNN_GRU: return launch_split_kind<CET_RNN_GRU>(m, a, tiles, uw, s, occ);
-    default: return launch_split_kind<CET_RNN_LSTM>(m, a, tiles, uw, s, occ);
+    case CET_RNN_TANH: return launch_split_kind<CET_RNN_TANH>(m, a, tiles, pl, s, occ);
+    case CET_RNN_GRU: return launch_split_kind<CET_RNN_GRU>(m, a, tiles, pl, s, occ);
+    default: return launch_split_kind<CET_RNN_LSTM>(m, a, tiles, pl, s, occ);
   }
 }
 
+// split_occ: [0..2] one tile per workgroup with 4, 8, 16 units, [3] two tiles with 16 units
 static int rnn_split_occupancy(RnnModel* m) {
   const SArgs none{};
-  for (int k = 0; k < 3; ++k) {
-    int occ = 1;
-    if (const int rc = split_kind_dispatch(m, none, 0, 4 << k, nullptr, &occ)) return rc;
-    m->split_occ[k] = occ < 1 ? 1 : occ;
+  const SplitPlan plans[4] = {{4, 1}, {8, 1}, {16, 1}, {16, 2}};
+  for (int k = 0; k < 4; ++k) {
+    int occ[2] = {1, 0};
+    if (const int rc = split_kind_dispatch(m, none, 0, plans[k], nullptr, occ)) return rc;
+    m->split_occ[k] = occ[0] < 1 ? 1 : occ[0];
+    m->split_spill[k] = occ[1];
   }
   return CET_OK;
 }
 
-// Workgroups of a launch with `uw` hidden units per workgroup that are resident at once, with one
-// workgroup per CU or with as many as fit (at most SPLIT_MAX_OCC).
-static long split_capacity(const RnnModel* m, int uw, bool shared_cu) {
-  const int occ = m->split_occ[uw == 4 ? 0 : (uw == 8 ? 1 : 2)];
+// Workgroups of a launch laid out as `pl` that are resident at once, with one workgroup per CU or
+// with as many as fit (at most SPLIT_MAX_OCC).
+static long split_capacity(const RnnModel* m, SplitPlan pl, bool shared_cu) {
+  const int occ = m->split_occ[pl.tpw == 2 ? 3 : (pl.uw == 4 ? 0 : (pl.uw == 8 ? 1 : 2))];
   return (long)m->cus * (shared_cu ? (occ < SPLIT_MAX_OCC ? occ : SPLIT_MAX_OCC) : 1);
 }
+static long split_workgroups(const RnnModel* m, int tiles, SplitPlan pl) {
+  return (long)((tiles + pl.tpw - 1) / pl.tpw) * (m->H / pl.uw);
+}
 
-// Hidden units per workgroup for a launch of `tiles` sequence tiles (0: the tiles do not fit one
-// launch). With a CU to itself a workgroup is fastest, so first the finest split that fits one
-// workgroup per CU (a small batch spreads over the whole device; the tanh cell has one row group
-// and gains nothing below 16); else the coarsest split whose workgroups fit two to a CU: they run
-// in step and share the MFMA pipes, so two to a CU only pay where the alternative is a second launch
-// (256 sequences of 256 hidden units, two layers: 16 units and one per CU 0.22 / 0.24 ms for GRU /
-// LSTM, 8 units and two per CU 0.25 / 0.25 ms; the tanh cell fits two to a CU at 16 units: 512
-// sequences in 0.18 ms instead of 0.30).
-static int split_units(const RnnModel* m, int tiles) {
-  for (int uw = m->kind == CET_RNN_TANH ? 16 : 4; uw <= 16; uw *= 2)
-    if ((long)tiles * (m->H / uw) <= split_capacity(m, uw, false)) return uw;
-  for (int uw = 16; uw >= (m->kind == CET_RNN_TANH ? 16 : 4); uw /= 2)
-    if ((long)tiles * (m->H / uw) <= split_capacity(m, uw, true)) return uw;
-  return 0;
+// The layout for a launch of `tiles` sequence tiles (uw 0: they do not fit one launch). With a CU to
+// itself a workgroup is fastest, so first the finest split that fits one workgroup per CU (a small
+// batch spreads over the whole device; the tanh cell has one row group and gains nothing below
+// 16). Beyond that (more than 256 sequences at 256 hidden units): for the tanh cell two workgroups
+// of 16 units per CU, where they fit, else two tiles per workgroup, which take turns so that one's
+// matrix work covers the other's exchange. Two workgroups to a CU of one launch run in step and
+// share the MFMA pipes, so they only pay where the matrix work is short (tanh cell: 512 sequences in
+// 0.18 ms) or the alternative is a second launch (256 sequences, GRU / LSTM: 16 units and one per
+// CU 0.22 / 0.24 ms, 8 units and two per CU 0.25 / 0.25 ms).
+static SplitPlan split_plan(const RnnModel* m, int tiles) {
+  const bool tanh_cell = m->kind == CET_RNN_TANH;
+  for (int uw = tanh_cell ? 16 : 4; uw <= 16; uw *= 2)
+    if (split_workgroups(m, tiles, {uw, 1}) <= split_capacity(m, {uw, 1}, false)) return {uw, 1};
+  if (tanh_cell && split_workgroups(m, tiles, {16, 1}) <= split_capacity(m, {16, 1}, true)) return {16, 1};
+  // (not where two tiles' state costs the compiler registers it has to spill: LSTM, 3 layers of 256)
+  if (m->split_spill[3] <= 256 && split_workgroups(m, tiles, {16, 2}) <= split_capacity(m, {16, 2}, false))
+    return {16, 2};
+  for (int uw = 16; uw >= (tanh_cell ? 16 : 4); uw /= 2)
+    if (split_workgroups(m, tiles, {uw, 1}) <= split_capacity(m, {uw, 1}, true)) return {uw, 1};
+  return {0, 1};
+}
+
+// The largest launch, and up to which batch a sequence of such launches beats the batch-tiled
+// kernel, whose time does not depend on the batch up to one tile per CU. Both times per time step
+// from a model fitted to measurements (MI355X; hidden 128 / 256, 1 to 3 layers, all three cells;
+// tools/rnnshapes.py, within 15 %):
+//   batch-tiled: 0.115 us per (k block of 8, gate, unit tile of a wave),
+//   hidden-split: 13.3 ns per MFMA a wave issues (32 cycles) + per layer 2.4 us of exchange and
+//   fixed work (3.6 us for two tiles taking turns) + 0.6 (1.0) us per step.
+static void rnn_split_limits(RnnModel* m) {
+  int tiles = 0;
+  while (tiles < 4096 && split_plan(m, tiles + 1).uw) ++tiles;
+  m->split_chunk = tiles * ST;
+  m->split_max_batch = 0;
+  if (!tiles) return;
+  const SplitPlan pl = split_plan(m, tiles);
+  const int G = gates_of(m->kind), H = m->H;
+  const bool shared = split_workgroups(m, tiles, pl) > m->cus;  // two workgroups to a CU share its MFMA pipes
+  const int sets = pl.uw == 16 ? G : (pl.uw == 8 ? 2 : 1);      // weight register sets per k block
+  double tiled = 0.0, split = pl.tpw == 2 ? 1.0 : 0.6;
+  for (int l = 0; l < m->layers; ++l) {
+    tiled += 0.115 * (H / 128) * G * (l == 0 ? 4 + H / 8 : 2 * H / 8);
+    const int blocks = l == 0 ? 2 + H / 16 : 2 * H / 16;  // k blocks of 16, a quarter per wave
+    const int mfma = (blocks + 3) / 4 * sets * 4;
+    split += (pl.tpw == 2 ? 3.6 : 2.4) + 0.0133 * mfma * (pl.tpw == 2 || shared ? 2 : 1);
+  }
+  int chunks = (int)(0.95 * tiled / split);
+  if (chunks < 1) chunks = 1;
+  m->split_max_batch = chunks * m->split_chunk;
 }
 
 // Whether the hidden-split kernel takes a batch in one launch: all its workgroups resident at once
@@ -1251,7 +1364,7 @@ static int split_tiles(int B) { return (B + ST - 1) / ST; }
 static bool split_fits(const RnnModel* m, int B, long max_wg16) {
   const int tiles = split_tiles(B);
   if ((long)tiles * (m->H / 16) > max_wg16) return false;
-  const int uw = split_units(m, tiles);
+  const int uw = split_plan(m, tiles).uw;
   if (!uw) return false;
   const int ns = m->H / uw > 16 ? m->H / uw / 16 : 1;
   return (size_t)tiles * m->layers * ns <= SPLIT_CNT_SLOTS;  // the last slot is the failure flag
@@ -1282,16 +1395,16 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
   a.hx = scratch + SPLIT_CNT_FLOATS;
   CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
   const int tiles = split_tiles(B);
-  const int uw = split_units(m, tiles);
-  if (!uw) return CET_ERR_TOO_LARGE;
+  const SplitPlan plan = split_plan(m, tiles);
+  if (!plan.uw) return CET_ERR_TOO_LARGE;
 #ifdef CET_PROF
   static unsigned long long* sp_dev = nullptr;
-  const int sp_wg = tiles * (m->H / uw);
+  const int sp_wg = (int)split_workgroups(m, tiles, plan);
   if (!sp_dev) CET_HIP(hipMalloc(&sp_dev, 1024 * SP_WORDS * sizeof(unsigned long long)));
   CET_HIP(hipMemsetAsync(sp_dev, 0, 1024 * SP_WORDS * sizeof(unsigned long long), stream));
   a.prof = sp_wg <= 1024 ? sp_dev : nullptr;
 #endif
-  const int rc = split_kind_dispatch(m, a, tiles, uw, stream, nullptr);
+  const int rc = split_kind_dispatch(m, a, tiles, plan, stream, nullptr);
   if (rc != CET_OK) return rc;
 #ifdef CET_PROF
   if (a.prof && getenv("CET_SPLIT_PROF")) {
@@ -1365,29 +1478,20 @@ int rnn_rollout_static(const RnnModel* m, const float* x, float* out, int B, int
 }
 
 // Sequences one launch of the hidden-split kernel takes on this handle's device (whole tiles).
-static int split_chunk(const RnnModel* m) {
-  long tiles = 0;
-  for (int uw = m->kind == CET_RNN_TANH ? 16 : 4; uw <= 16; uw *= 2) {
-    const long t = split_capacity(m, uw, true) / (m->H / uw);
-    if (t > tiles) tiles = t;
-  }
-  return (int)tiles * ST;
-}
+static int split_chunk(const RnnModel* m) { return m->split_chunk; }
 
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream) {
   // Small and medium batches: hidden units split over workgroups (a batch-tiled rollout of 64
   // sequences keeps 2 of the CUs busy for as long as one of 8192 keeps all of them busy). One
-  // launch takes as many sequences as its workgroups are resident at once (256 at 256 hidden
-  // units for GRU and LSTM, 512 for the tanh cell, whose workgroups fit two to a CU); larger
-  // batches go through it in chunks, one launch after the other on the stream, for as long as that
-  // beats the batch-tiled kernel, whose time is the same from 32 to 8192 sequences (measured per
-  // full launch / per batch-tiled rollout, 2 layers of 256: GRU 0.22 / 2.0 ms, LSTM 0.24 / 2.6 ms,
-  // tanh 0.18 / 0.70 ms).
+  // launch takes as many sequences as its workgroups are resident at once, each with one or two
+  // sequence tiles (512 at 256 hidden units); larger batches go through it in chunks, one launch
+  // after the other on the stream, for as long as that beats the batch-tiled kernel, whose time is
+  // the same from 32 to 8192 sequences (rnn_split_limits(); measured per full launch / per
+  // batch-tiled rollout, 2 layers of 256: GRU 0.35 / 2.0 ms, LSTM 0.40 / 2.6 ms, tanh 0.18 /
+  // 0.70 ms).
   const int chunk = split_chunk(m);
-  const int n_chunks = chunk > 0 ? (B + chunk - 1) / chunk : 0;
-  const int max_chunks = m->kind == CET_RNN_TANH ? 3 : (m->kind == CET_RNN_GRU ? 8 : 10);
-  bool split = chunk > 0 && B > 0 && (m->variant >= 2 || (m->variant == 0 && n_chunks <= max_chunks));
+  bool split = chunk > 0 && B > 0 && (m->variant >= 2 || (m->variant == 0 && B <= m->split_max_batch));
   if (split) {
     // Under stream capture the launches would be replayed later, outside the pool's bookkeeping:
     // the batch-tiled kernel needs no buffer (cet_rnn_rollout_static serves captured small batches).

@@ -327,7 +327,7 @@ class _RecurrentBase(_DeviceWeights):
 
     def select_kernel(self, kernel):
         """Pins the rollout kernel (tests, timing): "tiled" (a workgroup takes 32 sequences and all
-        hidden units), "split" (small batches: 16 sequences and 16 hidden units per workgroup,
+        hidden units), "split" (small batches: 16 sequences and 4, 8 or 16 hidden units per workgroup,
         hidden states exchanged once per layer and step), "auto" (by batch size, the default) or
         "split_giveup" (tests: the hidden-split kernel abandons its exchange at once, so that the
         stand-by launch of the tiled kernel behind it computes the result)."""
