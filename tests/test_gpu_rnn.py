@@ -74,6 +74,32 @@ def test_large_batch_against_checker(name, oracle):
     assert m.test_data(x[:0], 5, "cuda").shape == (0, 5, 16)
 
 
+@pytest.mark.parametrize("cls,H,layers", [("GRU", 256, 2), ("LSTM", 256, 2), ("RNN", 256, 2), ("LSTM", 128, 3),
+                                           ("GRU", 256, 3), ("LSTM", 256, 1), ("GRU", 128, 1)])
+def test_every_layout_of_the_hidden_split_kernel(cls, H, layers, oracle):
+    """The hidden-split kernel lays a launch out by batch size: 4, 8 or 16 hidden units per
+    workgroup, one or two workgroups per CU, one or two sequence tiles per workgroup (the second
+    tile of the last workgroup group may be missing). Batch sizes on both sides of every switch,
+    ragged ones included, against the batch-tiled kernel on the same inputs and, for a sample,
+    against the CPU checker."""
+    kind = {"RNN": 0, "GRU": 1, "LSTM": 2}[cls]
+    torch.manual_seed(H + layers + kind)
+    m = getattr(cet, cls)(16, 32, H, layers).eval()
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(H * layers + kind)
+    x = rng.standard_normal((1100, 9, 16)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    tiled = m.select_kernel("tiled").test_data(xd, 6, "cuda")
+    scale = max(1.0, float(tiled.abs().max()))
+    m.select_kernel("split")
+    for B in (1, 16, 17, 64, 65, 128, 129, 256, 257, 300, 511, 512, 513, 1024, 1100):
+        out = m.test_data(xd[:B].contiguous(), 6, "cuda")
+        assert torch.isfinite(out).all(), B
+        assert (out - tiled[:B]).abs().max() < 1e-4 * scale, B
+    want = oracle.rnn_rollout(kind, 16, 32, H, layers, blobs.pack_rnn(sd, kind, 16, 32, H, layers), x[:40], 6)
+    assert np.abs(tiled[:40].cpu().numpy() - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
+
+
 ABS_100 = 1e-3  # bound of the 100-step closed loop, times the output scale
 
 
