@@ -560,7 +560,7 @@ def run_informer12(ctx, B, steps, warmup, steady=False):
                    "batch_per_gpu": B, "global_batch": B * ctx.n_gpus, "parallelism": f"dp{ctx.n_gpus}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "informer_kernel<3,2,1,false,6>", "kernel_ms": dev_s * 1e3,
+                     "kernel": "informer_kernel<3,2,1,false,4,3>", "kernel_ms": dev_s * 1e3,
                      "flop_per_launch": f12 * B, "flop_per_prediction": f12},
     }
 

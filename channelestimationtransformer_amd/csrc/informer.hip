@@ -564,13 +564,21 @@ DEV void tap(float*& taps, int B, int b, int rows, const Lane ln, const Act& x) 
 // pack_L > 0 (single tiles only): the tile holds two sequences of pack_L <= 8 rows, at rows
 // 0.. and 8..; a query then only admits the keys of its own sequence, and amap / amap2 are the
 // maps of the first / second sequence (Lq = Lk = 16 for the row bookkeeping).
-template <int RQ, int RK, bool QREG, int NHP = 4>
+// HPT = 3 (models of 9 to 12 heads with at most 5 features per head, QREG only): a tile holds
+// THREE heads, so that 12 heads fill four tiles like 8 heads of 8 features do, not six. Head j of
+// a tile has features 0..3 in register j of the query / key tile (one per lane group) and
+// feature 4 in register 3 of lane group j (qk3_pos()): its scores are register j and register 3
+// with the keys of the other lane groups zeroed, two MFMAs as before. Values and context have the
+// head's features at positions 5 j .. 5 j + 4 of the tile (position 15 is zero).
+template <int RQ, int RK, bool QREG, int NHP = 4, int HPT = 2>
 DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* Vb, int Lq,
                    int Lk, bool causal, const Lane ln, Act& ctx, float* amap,
                    int pack_L = 0, float* amap2 = nullptr, float* map_stage = nullptr) {
+  static_assert(HPT == 2 || (HPT == 3 && QREG), "three heads per tile: queries in registers only");
   constexpr int LDQ = ldq<NHP>();
-  // head pairs per group (a divisor of NHP)
-  constexpr int NP = (RQ * RK == 1) ? (NHP % 4 == 0 ? 4 : 2) : (RQ * RK == 2 ? 2 : 1);
+  // tiles per group (a divisor of NHP)
+  constexpr int NP = HPT == 3 ? (RQ * RK == 1 ? 2 : 1)
+                              : ((RQ * RK == 1) ? (NHP % 4 == 0 ? 4 : 2) : (RQ * RK == 2 ? 2 : 1));
   // softmax(scale * s) is evaluated as 2^(c s + bias - max) / sum with c = scale * log2(e);
   // bias is 0 for admitted keys and -inf for padded or (causal) future ones.
   const float c = ln.attn_c;  // float(1 / sqrt(d_keys)) * log2 e
@@ -616,7 +624,7 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
   }
 #pragma unroll
   for (int hp0 = 0; hp0 < NHP; hp0 += NP) {
-    f32x4 p[NP][2][RK][RQ];  // [pair][head of the pair][key tile][query tile]
+    f32x4 p[NP][HPT][RK][RQ];  // [tile][head of the tile][key tile][query tile]
     // ---- scores^T = K Q^T: lane (query 16*qt + c) holds keys 16*kt + 4*g + i ----
     if (QREG) {
       f32x4 kf[NP][RK];
@@ -630,16 +638,24 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
 #pragma unroll
       for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+        for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
-          for (int kt = 0; kt < RK; ++kt)
+          for (int kt = 0; kt < RK; ++kt) {
+            // three heads: the head's fifth feature sits in register 3 of lane group hh only
+            const float k3 = (HPT == 3 && ln.g == hh) ? kf[pi][kt][3] : 0.f;
 #pragma unroll
             for (int qt = 0; qt < RQ; ++qt) {
               f32x4 sc = zero4();
-              sc = mfma(kf[pi][kt][2 * hh], q[qt][hp0 + pi][2 * hh], sc);
-              sc = mfma(kf[pi][kt][2 * hh + 1], q[qt][hp0 + pi][2 * hh + 1], sc);
+              if (HPT == 3) {
+                sc = mfma(kf[pi][kt][hh], q[qt][hp0 + pi][hh], sc);
+                sc = mfma(k3, q[qt][hp0 + pi][3], sc);
+              } else {
+                sc = mfma(kf[pi][kt][2 * hh], q[qt][hp0 + pi][2 * hh], sc);
+                sc = mfma(kf[pi][kt][2 * hh + 1], q[qt][hp0 + pi][2 * hh + 1], sc);
+              }
               p[pi][hh][kt][qt] = sc;
             }
+          }
     } else {
       float2 kf[NP][2][RK], qf[NP][2][RQ];
 #pragma unroll
@@ -669,11 +685,11 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
             }
     }
     // ---- masked, scaled softmax over the keys of each query ----
-    float mx[NP][2][RQ], sum[NP][2][RQ];
+    float mx[NP][HPT][RQ], sum[NP][HPT][RQ];
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
           float m = -INFINITY;
@@ -688,13 +704,13 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) mx[pi][hh][qt] = group_max(mx[pi][hh][qt]);
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
           f32x4 sm = zero4();
@@ -712,19 +728,19 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt)
           sum[pi][hh][qt] = __builtin_amdgcn_rcpf(group_sum(sum[pi][hh][qt]));
 #pragma unroll
     for (int pi = 0; pi < NP; ++pi)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+      for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
         for (int qt = 0; qt < RQ; ++qt) {
 #pragma unroll
           for (int kt = 0; kt < RK; ++kt) p[pi][hh][kt][qt] *= sum[pi][hh][qt];
-          const int head = 2 * (hp0 + pi) + hh;
+          const int head = HPT * (hp0 + pi) + hh;
           if (mapb && head < ln.n_heads) {
             const unsigned hoff = (unsigned)(head * map_hl) * 4u;  // wave-uniform: the head's map
             if (pack_L) {
@@ -766,12 +782,22 @@ DEV void attention(const Act& q, const float* Qb, const float* Kb, const float* 
       for (int kt = 0; kt < RK; ++kt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float v0 = upper ? 0.f : vf[pi][kt][i];
-          const float v1 = upper ? vf[pi][kt][i] : 0.f;
+          if (HPT == 3) {
+            const int hsel = (ln.c * 13) >> 6;  // c / 5 for c < 16: the head this lane's feature belongs to
 #pragma unroll
-          for (int qt = 0; qt < RQ; ++qt) {
-            acc[qt] = mfma(v0, p[pi][0][kt][qt][i], acc[qt]);
-            acc[qt] = mfma(v1, p[pi][1][kt][qt][i], acc[qt]);
+            for (int hh = 0; hh < HPT; ++hh) {
+              const float vh = hsel == hh ? vf[pi][kt][i] : 0.f;
+#pragma unroll
+              for (int qt = 0; qt < RQ; ++qt) acc[qt] = mfma(vh, p[pi][hh][kt][qt][i], acc[qt]);
+            }
+          } else {
+            const float v0 = upper ? 0.f : vf[pi][kt][i];
+            const float v1 = upper ? vf[pi][kt][i] : 0.f;
+#pragma unroll
+            for (int qt = 0; qt < RQ; ++qt) {
+              acc[qt] = mfma(v0, p[pi][0][kt][qt][i], acc[qt]);
+              acc[qt] = mfma(v1, p[pi][1][kt][qt][i], acc[qt]);
+            }
           }
         }
 #pragma unroll
@@ -916,7 +942,7 @@ DEV void decoder_layer(const float* __restrict__ w, Stage& st, float* smem, int 
 // fragments of every product are requested one product ahead, into two fragment sets used in
 // turn (A, B), so that they travel from L2 during the MFMAs of the product before. Same products,
 // same operand order, same results as encoder_layer / decoder_layer.
-template <int RT, int NHP>
+template <int RT, int NHP, int HPT>
 DEV void encoder_layer_ahead(const float* __restrict__ w, float* smem, int R, const Lane ln, int L,
                              int activation, float* amap, Act& x) {
   constexpr int SZ_ATTN = sz_attn<NHP>(), SZ_QKV = sz_qkv<NHP>(), LDQ = ldq<NHP>();
@@ -936,8 +962,8 @@ DEV void encoder_layer_ahead(const float* __restrict__ w, float* smem, int R, co
   wave_sync();
   PROF_MARK(ln, P_QKV);
   // no fragment set is held across the attention, which needs every register itself
-  attention<RT, RT, true, NHP>(q, nullptr, region_k<true, NHP>(smem, R), region_v<true, NHP>(smem, R), L, L,
-                               false, ln, y, amap);
+  attention<RT, RT, true, NHP, HPT>(q, nullptr, region_k<true, NHP>(smem, R), region_v<true, NHP>(smem, R), L,
+                                    L, false, ln, y, amap);
   PROF_MARK(ln, P_ATTN);
   wload<4, NHP>(B, w + 3 * SZ_QKV, ln);            // output projection
   wload<4, 4>(A, w + SZ_ATTN, ln);                 // conv1
@@ -958,7 +984,7 @@ DEV void encoder_layer_ahead(const float* __restrict__ w, float* smem, int R, co
   PROF_MARK(ln, P_ADDLN);
 }
 
-template <int RD, int RM, int NHP>
+template <int RD, int RM, int NHP, int HPT>
 DEV void decoder_layer_ahead(const float* __restrict__ w, float* smem, int R, const Lane ln, int Ld,
                              int Lm, int activation, const Act& mem, Act& x) {
   constexpr int SZ_ATTN = sz_attn<NHP>(), SZ_QKV = sz_qkv<NHP>(), LDQ = ldq<NHP>();
@@ -982,7 +1008,7 @@ DEV void decoder_layer_ahead(const float* __restrict__ w, float* smem, int R, co
   store_rows<RD, NHP, LDQ>(Vb, ln, t, Ld);
   wave_sync();
   PROF_MARK(ln, P_QKV);
-  attention<RD, RD, true, NHP>(q, nullptr, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
+  attention<RD, RD, true, NHP, HPT>(q, nullptr, Kb, Vb, Ld, Ld, true, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
   wload<4, NHP>(B, w + 3 * SZ_QKV, ln);
   wload<NHP, 4>(A, wc, ln);                        // cross query projection
@@ -1003,7 +1029,7 @@ DEV void decoder_layer_ahead(const float* __restrict__ w, float* smem, int R, co
   store_rows<RM, NHP, LDQ>(Vb, ln, t, Lm);
   wave_sync();
   PROF_MARK(ln, P_QKV);
-  attention<RD, RM, true, NHP>(q, nullptr, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
+  attention<RD, RM, true, NHP, HPT>(q, nullptr, Kb, Vb, Ld, Lm, false, ln, y, nullptr);
   PROF_MARK(ln, P_ATTN);
   wload<4, NHP>(B, wc + 3 * SZ_QKV, ln);           // cross output projection
   wload<4, 4>(A, wf, ln);                          // conv1
@@ -1336,7 +1362,7 @@ struct Cursor {
 };
 
 // One encoder step on RT row tiles (RM: tiles of the memory).
-template <int RT, int RM, bool WG, bool QR, int NHP>
+template <int RT, int RM, bool WG, bool QR, int NHP, int HPT>
 DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem, int R, const Lane ln,
                 int b, Act& x, Act& mem) {
   const int L = op.L;
@@ -1346,7 +1372,7 @@ DEV void run_op(const Op op, const KArgs& a, Cursor& cu, Stage& st, float* smem,
       amap = cu.attn + (size_t)b * a.n_heads * L * L;
       cu.attn += (size_t)a.B * a.n_heads * L * L;
     }
-    if (!WG && QR) encoder_layer_ahead<RT, NHP>(cu.w, smem, R, ln, L, a.activation, amap, x);
+    if (!WG && QR) encoder_layer_ahead<RT, NHP, HPT>(cu.w, smem, R, ln, L, a.activation, amap, x);
     else encoder_layer<RT, WG, QR, NHP>(cu.w, st, smem, R, ln, L, a.activation, amap, x);
     if (!ABLATED(a, 8)) cu.w += sz_enc_layer<NHP>();
     tap<RT>(cu.taps, a.B, b, L, ln, x);
@@ -1470,16 +1496,18 @@ DEV void run_op_partner(const Op op, const KArgs& a, Cursor& cu, Stage& st, floa
 // WG = true: a workgroup is 8 waves that keep in step through the weight staging (Stage);
 // waves beyond the batch compute a copy of the last sequence and store nothing.
 // RE: row tiles of the longest encoder step (2: sequences of up to 30 slots; 3: up to 46).
-// NHP: head pairs (4: up to 8 heads, 6: up to 12). The instantiations with three row tiles or
-// six head pairs ("large": the one-wave shape only) get the register budget of one wave per SIMD.
-template <int RE, int RD, int NHP>
-constexpr bool large_shape() { return RE > 2 || RD > 2 || NHP > 4; }
-template <int RE, int RD, int RM, bool WG, int NHP>
+// NHP: 16-column tiles of the Q / K / V projections, HPT heads each (4 x 2: up to 8 heads; 6 x 2: up
+// to 12 heads of up to 8 features; 4 x 3: up to 12 heads of up to 5). The instantiations with three
+// row tiles or more than 8 heads ("large": the one-wave shape only) get the register budget of one
+// wave per SIMD.
+template <int RE, int RD, int NHP, int HPT>
+constexpr bool large_shape() { return RE > 2 || RD > 2 || NHP > 4 || HPT > 2; }
+template <int RE, int RD, int RM, bool WG, int NHP, int HPT = 2>
 __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
-                             (WG || large_shape<RE, RD, NHP>()) ? 1 : CET_WPS) void informer_kernel(const KArgs a) {
-  static_assert(!WG || (RE <= 2 && RD <= 2 && NHP == 4), "the workgroup shape serves the 64-wide, 8-head family");
+                             (WG || large_shape<RE, RD, NHP, HPT>()) ? 1 : CET_WPS) void informer_kernel(const KArgs a) {
+  static_assert(!WG || (RE <= 2 && RD <= 2 && NHP == 4 && HPT == 2), "the workgroup shape serves the 64-wide, 8-head family");
   // queries in registers (and Q / K projections with permuted rows, see attention<.., QREG>)
-  constexpr bool QR = WG || large_shape<RE, RD, NHP>();
+  constexpr bool QR = WG || large_shape<RE, RD, NHP, HPT>();
   extern __shared__ __attribute__((aligned(16))) float smem_all[];
   const int lane = threadIdx.x & 63;
   const int wave = WG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
@@ -1546,10 +1574,10 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
   // ---- encoder stack (encoder.py:87-101) ---------------------------------------------
   int i = 0;
   if (RE > 2)
-    for (; i < a.n_ops3; ++i) run_op<RE, RM, WG, QR, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
-  for (; i < a.n_ops2; ++i) run_op<2, RM, WG, QR, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+    for (; i < a.n_ops3; ++i) run_op<RE, RM, WG, QR, NHP, HPT>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  for (; i < a.n_ops2; ++i) run_op<2, RM, WG, QR, NHP, HPT>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
   const int n_plain = WG ? a.n_pack0 : a.n_ops;
-  for (; i < n_plain; ++i) run_op<1, RM, WG, QR, NHP>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
+  for (; i < n_plain; ++i) run_op<1, RM, WG, QR, NHP, HPT>(a.ops[i], a, cu, st, smem, R, ln, b, x, mem);
   if (WG && i < a.n_ops) {
     // hand the partner's rows to the primary (see "two sequences in one tile")
     const int L0 = a.ops[i].L;
@@ -1595,7 +1623,7 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
     PROF_MARK(ln, P_EMBED);
   }
   for (int l = 0; l < a.d_layers; ++l) {
-    if (!WG && QR) decoder_layer_ahead<RD, RM, NHP>(cu.w, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
+    if (!WG && QR) decoder_layer_ahead<RD, RM, NHP, HPT>(cu.w, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
     else decoder_layer<RD, RM, WG, QR, NHP>(cu.w, st, smem, R, ln, Ld, a.mem_rows, a.activation, mem, x);
     if (!ABLATED(a, 8)) cu.w += sz_dec_layer<NHP>();
     tap<RD>(cu.taps, a.B, b, Ld, ln, x);
@@ -1655,7 +1683,11 @@ struct InformerModel {
 };
 
 // Head pairs the kernels run a model with: 4 (up to 8 heads) or 6 (up to 12).
-static int head_pairs(const cet_informer_cfg& c) { return c.n_heads <= 8 ? 4 : 6; }
+// Heads per 16-column tile of the Q / K / V projections and the number of such tiles: two heads of
+// up to 8 features (4 tiles for up to 8 heads, 6 for up to 12), or, for 9 to 12 heads of at most 5
+// features, three to a tile (4 tiles).
+static int heads_per_tile(const cet_informer_cfg& c) { return c.n_heads > 8 && c.d_model / c.n_heads <= 5 ? 3 : 2; }
+static int head_pairs(const cet_informer_cfg& c) { return c.n_heads <= 8 || heads_per_tile(c) == 3 ? 4 : 6; }
 
 // Steps of the encoder stack (encoder.py:87-101) into a.ops / n_ops / n_ops2 / n_ops3 / mem_rows.
 static void encoder_steps(const Dims& d, KArgs& a) {
@@ -1694,11 +1726,11 @@ static void encoder_steps(const Dims& d, KArgs& a) {
 static bool large_model(const cet_informer_cfg& c, const Dims& d) {
   KArgs a{};
   encoder_steps(d, a);
-  return head_pairs(c) > 4 || a.n_ops3 > 0 || d.seq_len > 32 || d.label_len + d.pred_len > 32;
+  return c.n_heads > 8 || a.n_ops3 > 0 || d.seq_len > 32 || d.label_len + d.pred_len > 32;
 }
 
 static bool supported(const cet_informer_cfg& c) {
-  // models run zero-padded to the kernels' 64 features and 8 or 12 heads of 8 features (widen())
+  // models run zero-padded to the kernels' 64 features and head layouts (widen())
   if (c.n_heads < 1 || c.n_heads > 12 || c.d_model < c.n_heads || c.d_model > DM) return false;
   if (c.d_model / c.n_heads > HDIM || c.d_ff < 1 || c.d_ff > DM) return false;
   if (c.enc_in != 16 && c.enc_in != 32) return false;
@@ -1783,6 +1815,10 @@ static int qk_pos(int f) {
   return 16 * t + 4 * ((r >> 1) & 3) + 2 * (r >> 3) + (r & 1);
 }
 
+// Three heads to a tile: dimension e < 5 of head j < 3 of the tile sits at position 4 e + j
+// (register j of lane group e) for e < 4 and at 4 j + 3 (register 3 of lane group j) for e = 4.
+static int qk3_pos(int j, int e) { return e < 4 ? 4 * e + j : 4 * j + 3; }
+
 // [out][in][3] (PyTorch Conv1d) -> [3][out][in]
 static void conv_taps_major(const float* src, int cout, int cin, std::vector<float>& dst) {
   for (int j = 0; j < 3; ++j)
@@ -1792,18 +1828,30 @@ static void conv_taps_major(const float* src, int cout, int cin, std::vector<flo
 
 // Zero-pads a model to the layout the kernels are built for, in the caller's tensor order: 64
 // model and FFN features (d and f keep their index), and 8 features per head, dimension e of
-// head h at 8 h + e of a Q / K / V row of HQ = 16 * head_pairs features. Padded rows / columns,
+// head h at 8 h + e of a Q / K / V row of HQ = 16 * head_pairs features (9 to 12 heads of at most
+// 5 features: three heads to a 16-feature tile, 5 positions each, see attention<.., HPT>). Padded rows / columns,
 // biases, LayerNorm and BatchNorm scales are zero (BatchNorm variance one), so padded features
 // are exactly zero everywhere; LayerNorm and the attention scale take the real sizes from the
 // kernel arguments. A 64-wide model with 8 heads of 8 comes out as it went in.
 // qk_permuted (large models, whose kernels keep the queries in registers): the output rows of
-// every query and key projection are stored in the order of qk_row().
+// every query and key projection are stored in the order of qk_row() (qk3_pos() with three heads
+// to a tile).
 static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const float* p, bool qk_permuted) {
   const int D = c.d_model, F = c.d_ff, E = D / c.n_heads, HE = E * c.n_heads;
   const int HQ = 16 * head_pairs(c);
   std::vector<float> v;
   auto ident = [](int i) { return i; };
-  auto head = [E](int i) { return (i / E) * HDIM + i % E; };
+  const int HPT = heads_per_tile(c);
+  // position of dimension e of head h in a value / context row
+  auto head = [E, HPT](int i) {
+    const int h = i / E, e = i % E;
+    return HPT == 3 ? (h / 3) * 16 + (h % 3) * 5 + e : h * HDIM + e;
+  };
+  // ... and in a permuted query / key row
+  auto qk_head = [E, HPT](int i) {
+    const int h = i / E, e = i % E;
+    return HPT == 3 ? (h / 3) * 16 + qk3_pos(h % 3, e) : qk_pos(h * HDIM + e);
+  };
   // matrix [rows][cols][taps] -> [R][C][taps]
   auto mat = [&](int rows, int cols, int taps, int R, int C, auto rmap, auto cmap) {
     const size_t base = v.size();
@@ -1823,9 +1871,8 @@ static std::vector<float> widen(const cet_informer_cfg& c, const Dims& d, const 
   auto attn = [&]() {
     for (int k = 0; k < 3; ++k) {
       if (qk_permuted && k < 2) {
-        auto hq = [&](int i) { return qk_pos(head(i)); };
-        mat(HE, D, 1, HQ, DM, hq, ident);
-        vec(HE, hq, 0.f, HQ);
+        mat(HE, D, 1, HQ, DM, qk_head, ident);
+        vec(HE, qk_head, 0.f, HQ);
       } else {
         mat(HE, D, 1, HQ, DM, head, ident);
         vec(HE, head, 0.f, HQ);
@@ -2149,21 +2196,22 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     // large shapes: decoder and memory row tiles as the model needs them (a 25-row decoder on
     // three tiles would issue 2.25 times the attention work of two)
     const int rd = Ld > 32 ? 3 : (Ld > 16 ? 2 : 1);
-#define CET_LAUNCH_LARGE(RD_, RM_, NHP_) \
-  hipLaunchKernelGGL((informer_kernel<3, RD_, RM_, false, NHP_>), grid, block, lds, stream, a)
-#define CET_LAUNCH_LARGE_RM(RD_, NHP_)            \
-  do {                                            \
-    if (m2) CET_LAUNCH_LARGE(RD_, 2, NHP_);       \
-    else CET_LAUNCH_LARGE(RD_, 1, NHP_);          \
+#define CET_LAUNCH_LARGE(RD_, RM_, NHP_, HPT_) \
+  hipLaunchKernelGGL((informer_kernel<3, RD_, RM_, false, NHP_, HPT_>), grid, block, lds, stream, a)
+#define CET_LAUNCH_LARGE_RM(RD_, NHP_, HPT_)            \
+  do {                                                  \
+    if (m2) CET_LAUNCH_LARGE(RD_, 2, NHP_, HPT_);       \
+    else CET_LAUNCH_LARGE(RD_, 1, NHP_, HPT_);          \
   } while (0)
-#define CET_LAUNCH_LARGE_RD(NHP_)                      \
-  do {                                                 \
-    if (rd == 3) CET_LAUNCH_LARGE_RM(3, NHP_);         \
-    else if (rd == 2) CET_LAUNCH_LARGE_RM(2, NHP_);    \
-    else CET_LAUNCH_LARGE_RM(1, NHP_);                 \
+#define CET_LAUNCH_LARGE_RD(NHP_, HPT_)                      \
+  do {                                                       \
+    if (rd == 3) CET_LAUNCH_LARGE_RM(3, NHP_, HPT_);         \
+    else if (rd == 2) CET_LAUNCH_LARGE_RM(2, NHP_, HPT_);    \
+    else CET_LAUNCH_LARGE_RM(1, NHP_, HPT_);                 \
   } while (0)
-    if (large && NHP == 6) CET_LAUNCH_LARGE_RD(6);
-    else if (large) CET_LAUNCH_LARGE_RD(4);
+    if (large && NHP == 6) CET_LAUNCH_LARGE_RD(6, 2);
+    else if (large && heads_per_tile(m->cfg) == 3) CET_LAUNCH_LARGE_RD(4, 3);  // four tiles of three heads
+    else if (large) CET_LAUNCH_LARGE_RD(4, 2);
 #undef CET_LAUNCH_LARGE_RD
 #undef CET_LAUNCH_LARGE_RM
 #undef CET_LAUNCH_LARGE
