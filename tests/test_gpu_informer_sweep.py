@@ -85,6 +85,8 @@ WIDE_CONFIGS = [
     ("Informer", 64, 8, 44, 12, 4, 3, 1, True, 3),          # 44 -> 23 -> 13 rows, single encoder
     ("Informer", 64, 12, 20, 10, 6, 2, 2, False, 8),        # 12 heads, memory of 20 rows
     ("Informer", 32, 4, 36, 33, 3, 3, 1, True, 5),          # 4 heads of 8, 36 decoder rows
+    ("InformerStack", 58, 11, 30, 12, 5, 3, 2, True, 5),    # 11 heads of 5: three to a tile, the last tile two
+    ("Informer", 36, 9, 25, 10, 5, 2, 1, True, 6),          # 9 heads of 4: three to a tile, no fifth feature
 ]
 
 
