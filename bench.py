@@ -415,7 +415,8 @@ def run_rnn(ctx, kind, B, P, steps, warmup, cpu_baseline=False):
         "config": {"workload": f"{kind.upper()}(16,16,256,2).test_data, seq_len 25, pred_len {P}, shipped checkpoint",
                    "batch_per_gpu": B, "global_batch": B * ctx.n_gpus, "parallelism": f"dp{ctx.n_gpus}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "traffic": measured_traffic(kind, B) if P == 5 else None,  # profiled at pred_len 5
                      "kernel": "rnn_rollout_kernel", "kernel_ms": dev_s * 1e3, "flop_per_launch": flop},
     }
     out["nmse_check"] = rnn_nmse_check(kind, dev)
@@ -456,7 +457,8 @@ def run_lmmse(ctx, N, hs, steps, warmup, cpu_baseline=False):
                    "parallelism": f"dp{ctx.n_gpus}"},
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": gbs / PEAK_HBM_GBS,
-                     "traffic": measured_traffic("lmmse", N) if hs == 1 else None,
+                     "traffic": measured_traffic("lmmse", N) if hs == 1 and (Nr, Ns) == (16, 4)
+                     else (measured_traffic("lmmse_block", N) if hs == 14 and (Nr, Ns) == (16, 4) else None),
                      "kernel": "lmmse_tiled<16,4,2>" if hs == 1 else "lmmse_block<16,4,2>",
                      "kernel_ms": dev_s * 1e3, "bytes_per_launch": bytes_re * N},
         "ber": float(bits[0] / bits[1]),
@@ -559,7 +561,7 @@ def run_informer12(ctx, B, steps, warmup, steady=False):
                                "label_len20_pred_len5 checkpoint, output_attention=False",
                    "batch_per_gpu": B, "global_batch": B * ctx.n_gpus, "parallelism": f"dp{ctx.n_gpus}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic("informer12", B),
                      "kernel": "informer_kernel<3,2,1,false,4,3>", "kernel_ms": dev_s * 1e3,
                      "flop_per_launch": f12 * B, "flop_per_prediction": f12},
     }

@@ -21,8 +21,8 @@ INFORMER_IO = 25 * 16 * 4 + 15 * 16 * 4 + 5 * 16 * 4
 INFORMER_MAPS = 8 * sum(L * L for L in (25, 14, 8, 5, 5, 4, 3)) * 4
 # workload -> (kernel substring, bench.py arguments, units per launch, algorithmic bytes per unit)
 WORKLOADS = {
-    "informer": ("informer_kernel<2, 1, 1, true, 4>", "default (B=4096, output_attention=True)", 4096, INFORMER_IO + INFORMER_MAPS),
-    "informer_nomaps": ("informer_kernel<2, 1, 1, true, 4>", "--no-attention-maps (B=4096)", 4096, INFORMER_IO),
+    "informer": ("informer_kernel<2, 1, 1, true, 4, 2>", "default (B=4096, output_attention=True)", 4096, INFORMER_IO + INFORMER_MAPS),
+    "informer_nomaps": ("informer_kernel<2, 1, 1, true, 4, 2>", "--no-attention-maps (B=4096)", 4096, INFORMER_IO),
     "informer12": ("informer_kernel<3, 2, 1, false, 4, 3>", "--workload informer12 (B=4096, 12 heads, 35 slots)", 4096,
                    (35 + 25 + 5) * 16 * 4),
     "lstm": ("rnn_rollout_kernel", "--workload lstm --pred-len 5 (B=8192)", 8192, 25 * 16 * 4 + 5 * 16 * 4),
