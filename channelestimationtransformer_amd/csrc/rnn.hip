@@ -959,6 +959,220 @@ __global__ __launch_bounds__(256, (UW < 16 && TPW == 1) ? 2 : 1) void rnn_split_
   }
 }
 
+// ---- half-tile rollout for batches that leave half of the CUs idle ---------------------------
+// The batch-tiled kernel takes 32 sequences per workgroup and as long for 2,100 sequences (66 of
+// 256 CUs busy) as for 8,192. This form takes 16 (v_mfma_f32_16x16x4_f32: the sequences are the N
+// dimension) and is otherwise the same design: wave w owns the hidden units [w H / 4, (w + 1) H / 4)
+// of every layer, all gates, in tiles of 16 units; the wave's weights are one linear stream per
+// time step through a ring of D k-blocks of registers (a k-block here is 16 k values of 16 units:
+// 1 KiB per gate, four MFMAs); the cell update is lane-local; h of a layer lives in LDS for the B
+// operand; the decoder Linear takes the fresh h from registers. A workgroup issues half the MFMAs
+// per step and streams the same weights, so it needs twice the L2 bandwidth per CU (32 B / clock).
+constexpr int MT = 16;  // sequences per workgroup
+constexpr int mid_ring_depth(int kind, int H) { return kind == CET_RNN_TANH && H >= 256 ? 16 : 8; }
+
+template <int KIND, bool PART_H>
+DEV void kblock16(f32x4 (&acc)[Cell<KIND>::NACC], const f32x4 (&wt)[Cell<KIND>::G], const f32x4 bf) {
+  constexpr int G = Cell<KIND>::G;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int gt = 0; gt < G; ++gt) {
+      const int ai = (KIND == CET_RNN_GRU && gt == 2 && PART_H) ? 3 : gt;
+      acc[ai] = mfma16(wt[gt][i], bf[i], acc[ai]);
+    }
+}
+
+// acc += W_seg * act^T over nblk k-blocks of 16 (a multiple of D); `act`: this lane's activation
+// row (+ 4 g) in LDS. On entry ring slot d holds the segment's block d.
+template <int KIND, bool PART_H, int D>
+DEV void segment16(f32x4 (&acc)[Cell<KIND>::NACC], WRing<Cell<KIND>::G, D>& r, const float* act,
+                   const int nblk) {
+  f32x4 b[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) b[d] = ld4(act + 16 * d);
+  for (int kb = 0; kb < nblk; kb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      kblock16<KIND, PART_H>(acc, r.w[d], b[d]);
+      ring_refill(r, d);
+      if (kb + D + d < nblk) b[d] = ld4(act + 16 * (kb + D + d));
+      pin_order();
+    }
+  }
+}
+
+// The layer-0 input segment: D k-blocks in the stream of which the first nvalid <= 2 carry weights.
+template <int KIND, int D>
+DEV void segment_input16(f32x4 (&acc)[Cell<KIND>::NACC], WRing<Cell<KIND>::G, D>& r,
+                         const f32x4 (&b)[2], const int nvalid) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    if (d < 2) {
+      if (d < nvalid) kblock16<KIND, false>(acc, r.w[d], b[d < 2 ? d : 0]);
+    }
+    ring_refill(r, d);
+    pin_order();
+  }
+}
+
+template <int KIND, int H, int NL>
+__global__ __launch_bounds__(256) void rnn_mid_kernel(const RArgs a) {
+  constexpr int G = Cell<KIND>::G, NACC = Cell<KIND>::NACC;
+  constexpr int UTW = H / 64;      // unit tiles of 16 per wave
+  constexpr int HS = H + 4;        // LDS row stride of an h buffer
+  constexpr int XB = FP / 16;      // k-blocks of the (padded) features
+  constexpr bool LSTM = KIND == CET_RNN_LSTM, GRU = KIND == CET_RNN_GRU;
+  constexpr int D = mid_ring_depth(KIND, H);
+  static_assert((H / 16) % D == 0, "segment lengths must be multiples of the ring depth");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* part = smem;                       // [4][MT][PSTR] decoder partial sums
+  float* hbuf = part + 4 * MT * PSTR;       // [NL][MT][HS]
+  float* lbias = hbuf + NL * MT * HS;       // [NL][2][G*H]  (see RArgs::bias)
+
+  if (a.only_if != nullptr &&
+      __hip_atomic_load(a.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+    return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;  // sequence inside the tile; k group / unit group
+  const int b0 = blockIdx.x * MT;
+  const int bc = (b0 + c < a.B) ? b0 + c : a.B - 1;  // tail tile: replay the last sequence
+
+  WRing<G, D> ring;
+  ring.total = (unsigned)(UTW * (D + H / 16) + (NL - 1) * UTW * 2 * (H / 16)) * G * 1024;
+  ring.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wstream) + (size_t)wave * (ring.total / 4), 0, ring.total, 0x00020000);
+  ring.lane_off = lane * 16;
+  ring.off = 0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring_refill(ring, d);
+
+  for (int i = tid; i < (4 * MT * PSTR + NL * MT * HS) / 4; i += 256) st4(smem + 4 * i, f32x4{0, 0, 0, 0});
+  for (int i = tid; i < NL * 2 * G * H / 4; i += 256) st4(lbias + 4 * i, ld4(a.bias + 4 * i));
+
+  // decoder rows (features 16 ft + c) x this wave's units, for the whole rollout
+  f32x4 wd[UTW][XB];
+#pragma unroll
+  for (int u = 0; u < UTW; ++u)
+#pragma unroll
+    for (int ft = 0; ft < XB; ++ft)
+      wd[u][ft] = ld4(a.dec_w + (size_t)(16 * ft + c) * H + wave * (16 * UTW) + 16 * u + 4 * g);
+  f32x4 bd[XB];
+#pragma unroll
+  for (int ft = 0; ft < XB; ++ft) bd[ft] = ld4(a.dec_b + 16 * ft + 4 * g);
+
+  f32x4 cst[LSTM ? NL : 1][LSTM ? UTW : 1];  // LSTM cell state of this wave's units
+#pragma unroll
+  for (int l = 0; l < (LSTM ? NL : 1); ++l)
+#pragma unroll
+    for (int u = 0; u < (LSTM ? UTW : 1); ++u) cst[l][u] = f32x4{0, 0, 0, 0};
+
+  f32x4 xin[XB];  // this step's input: features 16 q + 4 g .. + 3 of sequence c
+#pragma unroll
+  for (int q = 0; q < XB; ++q) xin[q] = f32x4{0, 0, 0, 0};
+  auto load_x = [&](int idx, f32x4 (&dst)[XB]) {
+    const float* row = a.x + ((size_t)bc * a.seq_len + idx) * a.F;
+#pragma unroll
+    for (int q = 0; q < XB; ++q)
+      if (16 * q + 4 * g < a.F) dst[q] = ld4(row + 16 * q + 4 * g);
+  };
+  load_x(0, xin);
+  __syncthreads();
+
+  const int n_steps = a.seq_len + a.pred_len - 1;
+  for (int idx = 0; idx < n_steps; ++idx) {
+    f32x4 xnext[XB];
+#pragma unroll
+    for (int q = 0; q < XB; ++q) xnext[q] = xin[q];
+    if (idx + 1 < a.seq_len) load_x(idx + 1, xnext);
+    const bool decode = idx >= a.seq_len - 1;
+    f32x4 dec_acc[XB];
+#pragma unroll
+    for (int ft = 0; ft < XB; ++ft) dec_acc[ft] = f32x4{0, 0, 0, 0};
+
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const float* in_buf = hbuf + (l > 0 ? l - 1 : 0) * MT * HS;  // the layer below (l > 0)
+      float* hl = hbuf + l * MT * HS;
+      const float* bi = lbias + l * 2 * G * H;
+      const float* bh = bi + G * H;
+      f32x4 hnew[UTW];
+#pragma unroll
+      for (int u = 0; u < UTW; ++u) {
+        const int u0 = wave * (16 * UTW) + 16 * u;  // first unit of this tile
+        f32x4 acc[NACC];
+#pragma unroll
+        for (int gt = 0; gt < G; ++gt) acc[gt] = ld4(bi + gt * H + u0 + 4 * g);  // b_ih + b_hh, or b_in
+        if (GRU) acc[NACC - 1] = ld4(bh + 2 * H + u0 + 4 * g);                  // b_hn
+        if (l == 0)
+          segment_input16<KIND, D>(acc, ring, xin, (a.F + 15) / 16);
+        else
+          segment16<KIND, false, D>(acc, ring, in_buf + c * HS + 4 * g, H / 16);
+        segment16<KIND, true, D>(acc, ring, hl + c * HS + 4 * g, H / 16);
+
+        f32x4 hprev = {0, 0, 0, 0};
+        if (GRU) hprev = ld4(hl + c * HS + u0 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float hv;
+          if (KIND == CET_RNN_TANH) {
+            hv = tanhf_(acc[0][i]);
+          } else if (GRU) {
+            const float rg = sigmoidf_(acc[0][i]);
+            const float zg = sigmoidf_(acc[GRU ? 1 : 0][i]);
+            const float ng = tanhf_(acc[GRU ? 2 : 0][i] + rg * acc[NACC - 1][i]);
+            hv = (1.0f - zg) * ng + zg * hprev[i];
+          } else {
+            const float ig = sigmoidf_(acc[0][i]);
+            const float fg = sigmoidf_(acc[LSTM ? 1 : 0][i]);
+            const float gg = tanhf_(acc[LSTM ? 2 : 0][i]);
+            const float og = sigmoidf_(acc[LSTM ? 3 : 0][i]);
+            const float cv = __fadd_rn(__fmul_rn(fg, cst[LSTM ? l : 0][LSTM ? u : 0][i]), __fmul_rn(ig, gg));
+            cst[LSTM ? l : 0][LSTM ? u : 0][i] = cv;
+            hv = og * tanhf_(cv);
+          }
+          hnew[u][i] = hv;
+        }
+        // decoder Linear partial over this tile's units, straight from the registers
+        if (l == NL - 1 && decode) {
+#pragma unroll
+          for (int ft = 0; ft < XB; ++ft)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dec_acc[ft] = mfma16(wd[u][ft][i], hnew[u][i], dec_acc[ft]);
+        }
+      }
+      __syncthreads();  // every wave has finished reading the old h of this layer
+#pragma unroll
+      for (int u = 0; u < UTW; ++u) st4(hl + c * HS + wave * (16 * UTW) + 16 * u + 4 * g, hnew[u]);
+      if (l == NL - 1 && decode) {
+#pragma unroll
+        for (int ft = 0; ft < XB; ++ft) st4(part + (wave * MT + c) * PSTR + 16 * ft + 4 * g, dec_acc[ft]);
+      }
+      __syncthreads();
+    }
+
+    if (decode) {
+#pragma unroll
+      for (int q = 0; q < XB; ++q) {
+        f32x4 sm = bd[q];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sm += ld4(part + (w * MT + c) * PSTR + 16 * q + 4 * g);
+        xnext[q] = sm;
+      }
+      if (wave == 1 && b0 + c < a.B) {
+        float* dst = a.out + ((size_t)(b0 + c) * a.pred_len + (idx - (a.seq_len - 1))) * a.F;
+#pragma unroll
+        for (int q = 0; q < XB; ++q)
+          if (16 * q + 4 * g < a.F) st4(dst + 16 * q + 4 * g, xnext[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < XB; ++q) xin[q] = xnext[q];
+  }
+}
+
 // Scratch of the hidden-split kernel: arrival counters (one per tile and layer, in a block of
 // their own that is zeroed before every launch), then the exchange slices
 // [tile][layer][parity][unit group][256 floats].
@@ -980,7 +1194,7 @@ struct RnnModel {
   int kind, F, I, H, layers;
   float* dev = nullptr;  // one allocation; the pointers below point into it
   // bias: SArgs::bias (hidden-split kernel); bias_tiled: RArgs::bias
-  const float *wstream, *bias, *bias_tiled, *dec_w, *dec_b;
+  const float *wstream, *wstream_mid, *bias, *bias_tiled, *dec_w, *dec_b;
   // gate weights in their PyTorch layouts (hidden-split kernel); w_ih[0] with the encoder folded in
   const float *w_ih[3], *w_hh[3];
   int device = 0, cus = 0;
@@ -1117,6 +1331,28 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
                   stream.push_back(k < K ? W[((size_t)g * H + unit) * K + k] : 0.f);
                 }
         }
+  // the same for the half-tile kernel: unit tiles of 16, k-blocks of 16, [64 lanes][4] with lane
+  // (c, g) <-> W[unit0 + c][16 kb + 4 g + i]; the layer-0 input segment is padded to its ring depth
+  std::vector<float> stream_mid;
+  {
+    const int DM_ = mid_ring_depth(kind, H), UTW = H / 64;
+    for (int wave = 0; wave < 4; ++wave)
+      for (int l = 0; l < layers; ++l)
+        for (int u = 0; u < UTW; ++u)
+          for (int part = 0; part < 2; ++part) {
+            const float* W = part == 0 ? (l == 0 ? w_fold.data() : lw[l].w_ih) : lw[l].w_hh;
+            const int K = part == 0 ? (l == 0 ? F : H) : H;
+            const int nblk = part == 0 ? (l == 0 ? DM_ : H / 16) : H / 16;
+            for (int kb = 0; kb < nblk; ++kb)
+              for (int g = 0; g < G; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                  for (int i = 0; i < 4; ++i) {
+                    const int unit = wave * 16 * UTW + 16 * u + (lane & 15);
+                    const int k = 16 * kb + 4 * (lane >> 4) + i;
+                    stream_mid.push_back(k < K ? W[((size_t)g * H + unit) * K + k] : 0.f);
+                  }
+          }
+  }
   const float* dec_w = p; p += (size_t)F * H;
   const float* dec_b = p; p += F;
   if ((size_t)(p - w) != n) return CET_ERR_BLOB_SIZE;
@@ -1137,7 +1373,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     while (all.size() % 64) all.push_back(0.f);  // keep every block 256-byte aligned
     return off;
   };
-  const size_t o_stream = place(stream), o_bias = place(bias), o_bias_t = place(bias_tiled),
+  const size_t o_stream = place(stream), o_stream_mid = place(stream_mid), o_bias = place(bias),
+               o_bias_t = place(bias_tiled),
                o_dw = place(dw), o_db = place(db);
   size_t o_ih[3] = {0, 0, 0}, o_hh[3] = {0, 0, 0};
   for (int l = 0; l < layers; ++l) {
@@ -1152,7 +1389,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     delete m;
     return hip_fail(e);
   }
-  m->wstream = m->dev + o_stream; m->bias = m->dev + o_bias; m->bias_tiled = m->dev + o_bias_t;
+  m->wstream = m->dev + o_stream; m->wstream_mid = m->dev + o_stream_mid; m->bias = m->dev + o_bias;
+  m->bias_tiled = m->dev + o_bias_t;
   m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
   for (int l = 0; l < 3; ++l) {
     m->w_ih[l] = l < layers ? m->dev + o_ih[l] : nullptr;
@@ -1226,10 +1464,42 @@ static bool variant(int kind, int ut, int layers, PrepareFn* pf, LaunchFn* lf) {
   }
 }
 
+// The half-tile kernel's instantiations: prepare (dynamic LDS limit) or launch.
+template <int KIND, int H, int NL>
+static int mid_do(const RArgs* a, hipStream_t stream) {
+  const size_t lds = sizeof(float) * (size_t)(4 * MT * PSTR + NL * MT * (H + 4) + NL * 2 * Cell<KIND>::G * H);
+  if (!a) {
+    CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_mid_kernel<KIND, H, NL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return CET_OK;
+  }
+  hipLaunchKernelGGL((rnn_mid_kernel<KIND, H, NL>), dim3((unsigned)((a->B + MT - 1) / MT)), dim3(256), lds, stream, *a);
+  CET_HIP(hipGetLastError());
+  return CET_OK;
+}
+template <int KIND>
+static int mid_kind(const RnnModel* m, const RArgs* a, hipStream_t s) {
+#define CET_MID_CASE(H_, NL_) \
+  if (m->H == H_ && m->layers == NL_) return mid_do<KIND, H_, NL_>(a, s);
+  CET_MID_CASE(128, 1) CET_MID_CASE(128, 2) CET_MID_CASE(128, 3)
+  CET_MID_CASE(256, 1) CET_MID_CASE(256, 2) CET_MID_CASE(256, 3)
+#undef CET_MID_CASE
+  return CET_ERR_UNSUPPORTED;
+}
+// a == nullptr: prepare
+static int mid_dispatch(const RnnModel* m, const RArgs* a, hipStream_t s) {
+  switch (m->kind) {
+    case CET_RNN_TANH: return mid_kind<CET_RNN_TANH>(m, a, s);
+    case CET_RNN_GRU: return mid_kind<CET_RNN_GRU>(m, a, s);
+    default: return mid_kind<CET_RNN_LSTM>(m, a, s);
+  }
+}
+
 static int rnn_prepare(const RnnModel* m) {
   PrepareFn pf;
   LaunchFn lf;
   if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
+  if (const int rc = mid_dispatch(m, nullptr, nullptr)) return rc;
   return pf();
 }
 
@@ -1332,9 +1602,10 @@ static SplitPlan split_plan(const RnnModel* m, int tiles) {
 // kernel, whose time does not depend on the batch up to one tile per CU. Both times per time step
 // from a model fitted to measurements (MI355X; hidden 128 / 256, 1 to 3 layers, all three cells;
 // tools/rnnshapes.py, within 15 %):
-//   batch-tiled: 0.115 us per (k block of 8, gate, unit tile of a wave),
+//   batch-tiled: 0.115 us per (k block of 8, gate, unit tile of a wave); half-tile kernel: 0.56 of that,
 //   hidden-split: 13.3 ns per MFMA a wave issues (32 cycles) + per layer 2.4 us of exchange and
-//   fixed work (3.6 us for two tiles taking turns) + 0.6 (1.0) us per step.
+//   fixed work (2.1 us with two workgroups to a CU, 3.6 us for two tiles taking turns) + 0.6 (1.0)
+//   us per step.
 static void rnn_split_limits(RnnModel* m) {
   int tiles = 0;
   while (tiles < 4096 && split_plan(m, tiles + 1).uw) ++tiles;
@@ -1350,9 +1621,11 @@ static void rnn_split_limits(RnnModel* m) {
     tiled += 0.115 * (H / 128) * G * (l == 0 ? 4 + H / 8 : 2 * H / 8);
     const int blocks = l == 0 ? 2 + H / 16 : 2 * H / 16;  // k blocks of 16, a quarter per wave
     const int mfma = (blocks + 3) / 4 * sets * 4;
-    split += (pl.tpw == 2 ? 3.6 : 2.4) + 0.0133 * mfma * (pl.tpw == 2 || shared ? 2 : 1);
+    split += (pl.tpw == 2 ? 3.6 : (shared ? 2.1 : 2.4)) + 0.0133 * mfma * (pl.tpw == 2 || shared ? 2 : 1);
   }
+  // up to one half tile per CU the half-tile kernel stands in for the batch-tiled one at 0.56 of its time
   int chunks = (int)(0.95 * tiled / split);
+  if ((long)chunks * m->split_chunk <= (long)MT * m->cus) chunks = (int)(0.56 * tiled / split);
   if (chunks < 1) chunks = 1;
   m->split_max_batch = chunks * m->split_chunk;
 }
@@ -1491,7 +1764,8 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   // batch-tiled rollout, 2 layers of 256: GRU 0.35 / 2.0 ms, LSTM 0.40 / 2.6 ms, tanh 0.18 /
   // 0.70 ms).
   const int chunk = split_chunk(m);
-  bool split = chunk > 0 && B > 0 && (m->variant >= 2 || (m->variant == 0 && B <= m->split_max_batch));
+  bool split = chunk > 0 && B > 0 &&
+               (m->variant == 2 || m->variant == 3 || (m->variant == 0 && B <= m->split_max_batch));
   if (split) {
     // Under stream capture the launches would be replayed later, outside the pool's bookkeeping:
     // the batch-tiled kernel needs no buffer (cet_rnn_rollout_static serves captured small batches).
@@ -1522,6 +1796,12 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
     return rc;
   }
   RArgs a = tiled_args(m, x, out, B, seq_len, pred_len);
+  // Up to one half tile per CU the half-tile kernel (16 sequences per workgroup) takes 0.55 of the
+  // batch-tiled kernel's time; beyond, its second round of workgroups costs more than full tiles.
+  if (m->variant == 4 || (m->variant == 0 && B <= MT * m->cus)) {
+    a.wstream = m->wstream_mid;
+    return mid_dispatch(m, &a, stream);
+  }
 #ifdef CET_PROF
   static unsigned long long* prof_dev = nullptr;
   const size_t prof_bytes = (size_t)RP_SLOTS * 4 * RP_WORDS * sizeof(unsigned long long);

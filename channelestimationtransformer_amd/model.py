@@ -323,12 +323,13 @@ class _RecurrentBase(_DeviceWeights):
             _cabi.check(_cabi.lib().cet_rnn_select(h, choice), "cet_rnn_select")
         return h, None
 
-    _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3}
+    _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3, "half_tile": 4}
 
     def select_kernel(self, kernel):
         """Pins the rollout kernel (tests, timing): "tiled" (a workgroup takes 32 sequences and all
         hidden units), "split" (small batches: 16 sequences and 4, 8 or 16 hidden units per workgroup,
-        hidden states exchanged once per layer and step), "auto" (by batch size, the default) or
+        hidden states exchanged once per layer and step), "half_tile" (the tiled design with 16
+        sequences per workgroup, for batches of up to 16 per CU), "auto" (by batch size, the default) or
         "split_giveup" (tests: the hidden-split kernel abandons its exchange at once, so that the
         stand-by launch of the tiled kernel behind it computes the result)."""
         self._kernel_choice = self._KERNELS[kernel]

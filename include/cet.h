@@ -151,7 +151,7 @@ int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int 
 int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len,
                     int pred_len, void* stream);
 
-/* Pins the kernel of later rollouts of this handle (tests and timing): 0 by batch size, 1 the
+/* Pins the kernel of later rollouts of this handle (tests and timing; 0..4): 0 by batch size, 1 the
  * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
  * kernel for small batches (16 sequences and 4, 8 or 16 hidden units per workgroup - as few as
  * keeps the launch's workgroups resident at once, so that a small batch spreads over the whole
@@ -160,7 +160,9 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * count, twice that where two such workgroups fit a CU; larger batches go through it in chunks,
  * launch after launch - which choice 0 does for as long as it beats the batch-tiled kernel, a
  * few chunks), 3 the same with an exchange that gives up at its first
- * unanswered poll (tests: every chunk is then computed by the stand-by launch described next).
+ * unanswered poll (tests: every chunk is then computed by the stand-by launch described next), 4
+ * the half-tile kernel (the batch-tiled design with 16 sequences per workgroup: 0.55 of its time
+ * up to 16 sequences per CU, which is where choice 0 uses it above the hidden-split range).
  * Rollouts on the hidden-split kernel may overlap freely, on any streams and handles and from any
  * host threads: each call claims one of four exchange buffers per GPU (a call that finds all four in flight on other
  * streams queues its stream behind one of them), and behind every hidden-split launch the
