@@ -97,6 +97,11 @@ struct RArgs {
   // failure flag of the hidden-split rollout launched just before on the same stream).
   const unsigned* only_if;
   unsigned long long* prof;         // profiling build only
+  // shared half-tile kernel only: exchange area [tile][layer][parity][sequence][H], arrival counters
+  // [tile][layer] (zero at launch; the header's last word is the failure flag), polls before a wait gives up
+  float* hx;
+  unsigned* cnt;
+  int spin_limit;
 };
 
 // C/D row of register r for lane half hh (v_mfma_f32_32x32x2_f32): (r&3) + 8*(r>>2) + 4*hh.
@@ -455,8 +460,8 @@ constexpr int ST = 16;        // sequences per workgroup
 // 512-byte block every poll and every arrival of the whole grid went to one memory channel), and in
 // the last word the grid's failure flag.
 constexpr int CNT_STRIDE = 32;                 // words between counters
-constexpr size_t SPLIT_CNT_SLOTS = 255;        // counters the header has room for
-constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 32 KiB
+constexpr size_t SPLIT_CNT_SLOTS = 511;        // counters the header has room for
+constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 64 KiB
 constexpr int SPIN_LIMIT = 1 << 20;  // polls of about a microsecond each: a second or two
 
 DEV f32x4 mfma16(float a, float b, f32x4 c) {
@@ -1173,6 +1178,219 @@ __global__ __launch_bounds__(256) void rnn_mid_kernel(const RArgs a) {
   }
 }
 
+// ---- the half-tile rollout with a tile's hidden units shared by S workgroups --------------------
+// Between the hidden-split kernel's launches and one half tile per CU (about 600 to 2,000 sequences
+// at 256 hidden units) neither fills the device. Here workgroup (tile, s) takes the hidden units
+// [s H / S, (s + 1) H / S) of a 16-sequence tile: the half-tile kernel's streamed weights and
+// lane-local cell update on a 1 / S share of the units, and after every layer step the S workgroups
+// exchange their slices of h through global memory as the hidden-split kernel's do (agent-scope
+// 16-byte stores, every storing wave's wait, a workgroup barrier, one arrival per workgroup on the
+// (tile, layer) counter; a bounded poll, a barrier, agent-scope loads of the full state into LDS;
+// buffers alternate by step parity; a wait that runs out raises the failure flag and the batch-tiled
+// kernel, launched behind on stand-by, recomputes the batch). The decoder Linear needs all hidden
+// units, so every workgroup computes it from the fetched state, k split over its waves.
+template <int KIND, int H, int NL, int S>
+__global__ __launch_bounds__(256) void rnn_mid_shared_kernel(const RArgs a) {
+  constexpr int G = Cell<KIND>::G, NACC = Cell<KIND>::NACC;
+  constexpr int HU = H / S;        // hidden units of this workgroup
+  constexpr int UTW = HU / 64;     // unit tiles of 16 per wave
+  constexpr int HS = H + 4;        // LDS row stride of an h buffer
+  constexpr int XB = FP / 16;      // k-blocks of the (padded) features
+  constexpr int HB = H / 16;       // k-blocks of a hidden state
+  constexpr bool LSTM = KIND == CET_RNN_LSTM, GRU = KIND == CET_RNN_GRU;
+  constexpr int D = mid_ring_depth(KIND, H);
+  static_assert(UTW >= 1 && (H / 16) % D == 0, "16 units per wave at least; segments in multiples of the ring depth");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* part = smem;                       // [4][MT][PSTR] decoder partial sums
+  float* hbuf = part + 4 * MT * PSTR;       // [NL][MT][HS]
+  float* lbias = hbuf + NL * MT * HS;       // [NL][2][G*H]  (see RArgs::bias)
+  __shared__ int dead;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x / S, sh = blockIdx.x % S;
+  const int b0 = tile * MT;
+  const int bc = (b0 + c < a.B) ? b0 + c : a.B - 1;
+  const int unit_w = sh * HU + wave * (16 * UTW);  // first unit of this wave
+
+  WRing<G, D> ring;
+  ring.total = (unsigned)(UTW * (D + H / 16) + (NL - 1) * UTW * 2 * (H / 16)) * G * 1024;
+  ring.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wstream) + (size_t)(sh * 4 + wave) * (ring.total / 4), 0, ring.total, 0x00020000);
+  ring.lane_off = lane * 16;
+  ring.off = 0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) ring_refill(ring, d);
+
+  for (int i = tid; i < (4 * MT * PSTR + NL * MT * HS) / 4; i += 256) st4(smem + 4 * i, f32x4{0, 0, 0, 0});
+  for (int i = tid; i < NL * 2 * G * H / 4; i += 256) st4(lbias + 4 * i, ld4(a.bias + 4 * i));
+  if (tid == 0) dead = 0;
+
+  // decoder rows (features 16 ft + c) x this wave's k-blocks 4 j + wave of the top hidden state
+  f32x4 wd[XB][HB / 4];
+#pragma unroll
+  for (int ft = 0; ft < XB; ++ft)
+#pragma unroll
+    for (int j = 0; j < HB / 4; ++j)
+      wd[ft][j] = ld4(a.dec_w + (size_t)(16 * ft + c) * H + 16 * (4 * j + wave) + 4 * g);
+  f32x4 bd[XB];
+#pragma unroll
+  for (int ft = 0; ft < XB; ++ft) bd[ft] = ld4(a.dec_b + 16 * ft + 4 * g);
+
+  f32x4 cst[LSTM ? NL : 1][LSTM ? UTW : 1];
+#pragma unroll
+  for (int l = 0; l < (LSTM ? NL : 1); ++l)
+#pragma unroll
+    for (int u = 0; u < (LSTM ? UTW : 1); ++u) cst[l][u] = f32x4{0, 0, 0, 0};
+
+  f32x4 xin[XB];
+#pragma unroll
+  for (int q = 0; q < XB; ++q) xin[q] = f32x4{0, 0, 0, 0};
+  auto load_x = [&](int idx, f32x4 (&dst)[XB]) {
+    const float* row = a.x + ((size_t)bc * a.seq_len + idx) * a.F;
+#pragma unroll
+    for (int q = 0; q < XB; ++q)
+      if (16 * q + 4 * g < a.F) dst[q] = ld4(row + 16 * q + 4 * g);
+  };
+  load_x(0, xin);
+
+  constexpr int AGENT_SCOPE = 16;  // sc1
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t hx_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      a.hx + (size_t)tile * NL * 2 * H * MT, 0, NL * 2 * H * MT * 4, 0x00020000);
+  unsigned* const cnt_tile = a.cnt + (size_t)tile * NL * CNT_STRIDE;
+  unsigned* const fail = a.cnt + (SPLIT_CNT_FLOATS - 1);
+  __syncthreads();
+
+  const int n_steps = a.seq_len + a.pred_len - 1;
+  for (int idx = 0; idx < n_steps; ++idx) {
+    f32x4 xnext[XB];
+#pragma unroll
+    for (int q = 0; q < XB; ++q) xnext[q] = xin[q];
+    if (idx + 1 < a.seq_len) load_x(idx + 1, xnext);
+    const bool decode = idx >= a.seq_len - 1;
+
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const float* in_buf = hbuf + (l > 0 ? l - 1 : 0) * MT * HS;
+      float* hl = hbuf + l * MT * HS;
+      const float* bi = lbias + l * 2 * G * H;
+      const float* bh = bi + G * H;
+      f32x4 hnew[UTW];
+#pragma unroll
+      for (int u = 0; u < UTW; ++u) {
+        const int u0 = unit_w + 16 * u;
+        f32x4 acc[NACC];
+#pragma unroll
+        for (int gt = 0; gt < G; ++gt) acc[gt] = ld4(bi + gt * H + u0 + 4 * g);
+        if (GRU) acc[NACC - 1] = ld4(bh + 2 * H + u0 + 4 * g);
+        if (l == 0)
+          segment_input16<KIND, D>(acc, ring, xin, (a.F + 15) / 16);
+        else
+          segment16<KIND, false, D>(acc, ring, in_buf + c * HS + 4 * g, H / 16);
+        segment16<KIND, true, D>(acc, ring, hl + c * HS + 4 * g, H / 16);
+
+        f32x4 hprev = {0, 0, 0, 0};
+        if (GRU) hprev = ld4(hl + c * HS + u0 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float hv;
+          if (KIND == CET_RNN_TANH) {
+            hv = tanhf_(acc[0][i]);
+          } else if (GRU) {
+            const float rg = sigmoidf_(acc[0][i]);
+            const float zg = sigmoidf_(acc[GRU ? 1 : 0][i]);
+            const float ng = tanhf_(acc[GRU ? 2 : 0][i] + rg * acc[NACC - 1][i]);
+            hv = (1.0f - zg) * ng + zg * hprev[i];
+          } else {
+            const float ig = sigmoidf_(acc[0][i]);
+            const float fg = sigmoidf_(acc[LSTM ? 1 : 0][i]);
+            const float gg = tanhf_(acc[LSTM ? 2 : 0][i]);
+            const float og = sigmoidf_(acc[LSTM ? 3 : 0][i]);
+            const float cv = __fadd_rn(__fmul_rn(fg, cst[LSTM ? l : 0][LSTM ? u : 0][i]), __fmul_rn(ig, gg));
+            cst[LSTM ? l : 0][LSTM ? u : 0][i] = cv;
+            hv = og * tanhf_(cv);
+          }
+          hnew[u][i] = hv;
+        }
+      }
+      // ---- the own slice goes out: [sequence][H] rows of the (layer, parity) area ----
+      const unsigned so = (unsigned)((l * 2 + (idx & 1)) * H * MT) * 4u;
+#pragma unroll
+      for (int u = 0; u < UTW; ++u)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hnew[u]), hx_rsrc,
+                                               (unsigned)(c * H + unit_w + 16 * u + 4 * g) * 4u, so, AGENT_SCOPE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the arrival follows
+      __syncthreads();  // ... which also says that every wave has finished reading the old h of this layer
+      if (tid == 0) {
+        __hip_atomic_fetch_add(cnt_tile + l * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!dead) {
+          const unsigned target = (unsigned)S * (unsigned)(idx + 1);
+          int spins = 0;
+          while (__hip_atomic_load(cnt_tile + l * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > a.spin_limit) {
+              dead = 1;
+              __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      {  // the layer's full state: H MT / 4 pieces of 16 bytes, thread tid takes pieces tid + 256 r
+        constexpr int NPC = H * MT / 4 / 256;
+        u32x4 v[NPC];
+#pragma unroll
+        for (int r = 0; r < NPC; ++r)
+          v[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, (unsigned)(tid + 256 * r) * 16u, so, AGENT_SCOPE);
+#pragma unroll
+        for (int r = 0; r < NPC; ++r) {
+          const int p = tid + 256 * r;
+          st4(hl + (p / (H / 4)) * HS + 4 * (p % (H / 4)), __builtin_bit_cast(f32x4, v[r]));
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- decoder Linear on the new top hidden state: the prediction and the next input ----
+    if (decode) {
+      f32x4 dacc[XB];
+#pragma unroll
+      for (int ft = 0; ft < XB; ++ft) dacc[ft] = f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < HB / 4; ++j) {
+        const f32x4 bv = ld4(hbuf + (NL - 1) * MT * HS + c * HS + 16 * (4 * j + wave) + 4 * g);
+#pragma unroll
+        for (int ft = 0; ft < XB; ++ft)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dacc[ft] = mfma16(wd[ft][j][i], bv[i], dacc[ft]);
+      }
+#pragma unroll
+      for (int ft = 0; ft < XB; ++ft) st4(part + (wave * MT + c) * PSTR + 16 * ft + 4 * g, dacc[ft]);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < XB; ++q) {
+        f32x4 sm = bd[q];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sm += ld4(part + (w * MT + c) * PSTR + 16 * q + 4 * g);
+        xnext[q] = sm;
+      }
+      if (sh == 0 && wave == 1 && b0 + c < a.B) {
+        float* dst = a.out + ((size_t)(b0 + c) * a.pred_len + (idx - (a.seq_len - 1))) * a.F;
+#pragma unroll
+        for (int q = 0; q < XB; ++q)
+          if (16 * q + 4 * g < a.F) st4(dst + 16 * q + 4 * g, xnext[q]);
+      }
+      // `part` is written again only behind the barriers of the next step's layers
+    }
+#pragma unroll
+    for (int q = 0; q < XB; ++q) xin[q] = xnext[q];
+  }
+}
+
 // Scratch of the hidden-split kernel: arrival counters (one per tile and layer, in a block of
 // their own that is zeroed before every launch), then the exchange slices
 // [tile][layer][parity][unit group][256 floats].
@@ -1195,6 +1413,7 @@ struct RnnModel {
   float* dev = nullptr;  // one allocation; the pointers below point into it
   // bias: SArgs::bias (hidden-split kernel); bias_tiled: RArgs::bias
   const float *wstream, *wstream_mid, *bias, *bias_tiled, *dec_w, *dec_b;
+  const float* wstream_shared[3] = {nullptr, nullptr, nullptr};  // shared half-tile kernel, S = 2 and 4 at [1], [2]
   // gate weights in their PyTorch layouts (hidden-split kernel); w_ih[0] with the encoder folded in
   const float *w_ih[3], *w_hh[3];
   int device = 0, cus = 0;
@@ -1207,7 +1426,8 @@ struct RnnModel {
   int split_occ[4] = {1, 1, 1, 1};
   int split_spill[4] = {0, 0, 0, 0};  // scratch bytes per lane of the same instantiations
   int split_chunk = 0;      // sequences one launch of the hidden-split kernel takes at most
-  int split_max_batch = 0;  // largest batch the automatic choice gives to the hidden-split kernel
+  // estimated microseconds per time step of the batch-tiled kernel (any batch up to 32 per CU)
+  double est_tiled_step = 0.0;
 };
 constexpr int SPLIT_MAX_OCC = 2;
 
@@ -1353,6 +1573,30 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
                   }
           }
   }
+  // ... and for its shared form, one stream per (share of the units, wave): [share][wave][layer]...
+  std::vector<float> stream_shared[3];
+  for (int si = 1; si < 3; ++si) {
+    const int S = 1 << si;
+    if (H / S < 64) continue;  // a wave takes at least one tile of 16 units
+    const int DM_ = mid_ring_depth(kind, H), UTW = H / S / 64;
+    for (int sh = 0; sh < S; ++sh)
+      for (int wave = 0; wave < 4; ++wave)
+        for (int l = 0; l < layers; ++l)
+          for (int u = 0; u < UTW; ++u)
+            for (int part = 0; part < 2; ++part) {
+              const float* W = part == 0 ? (l == 0 ? w_fold.data() : lw[l].w_ih) : lw[l].w_hh;
+              const int K = part == 0 ? (l == 0 ? F : H) : H;
+              const int nblk = part == 0 ? (l == 0 ? DM_ : H / 16) : H / 16;
+              for (int kb = 0; kb < nblk; ++kb)
+                for (int g = 0; g < G; ++g)
+                  for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 4; ++i) {
+                      const int unit = sh * (H / S) + wave * 16 * UTW + 16 * u + (lane & 15);
+                      const int k = 16 * kb + 4 * (lane >> 4) + i;
+                      stream_shared[si].push_back(k < K ? W[((size_t)g * H + unit) * K + k] : 0.f);
+                    }
+            }
+  }
   const float* dec_w = p; p += (size_t)F * H;
   const float* dec_b = p; p += F;
   if ((size_t)(p - w) != n) return CET_ERR_BLOB_SIZE;
@@ -1376,6 +1620,9 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   const size_t o_stream = place(stream), o_stream_mid = place(stream_mid), o_bias = place(bias),
                o_bias_t = place(bias_tiled),
                o_dw = place(dw), o_db = place(db);
+  size_t o_shared[3] = {0, 0, 0};
+  for (int si = 1; si < 3; ++si)
+    if (!stream_shared[si].empty()) o_shared[si] = place(stream_shared[si]);
   size_t o_ih[3] = {0, 0, 0}, o_hh[3] = {0, 0, 0};
   for (int l = 0; l < layers; ++l) {
     o_ih[l] = place(l == 0 ? w_fold : std::vector<float>(lw[l].w_ih, lw[l].w_ih + (size_t)G * H * lw[l].in));
@@ -1391,6 +1638,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   m->wstream = m->dev + o_stream; m->wstream_mid = m->dev + o_stream_mid; m->bias = m->dev + o_bias;
   m->bias_tiled = m->dev + o_bias_t;
+  for (int si = 1; si < 3; ++si)
+    m->wstream_shared[si] = stream_shared[si].empty() ? nullptr : m->dev + o_shared[si];
   m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
   for (int l = 0; l < 3; ++l) {
     m->w_ih[l] = l < layers ? m->dev + o_ih[l] : nullptr;
@@ -1464,34 +1713,45 @@ static bool variant(int kind, int ut, int layers, PrepareFn* pf, LaunchFn* lf) {
   }
 }
 
-// The half-tile kernel's instantiations: prepare (dynamic LDS limit) or launch.
-template <int KIND, int H, int NL>
+// The half-tile kernel's instantiations (S = 1: a tile per workgroup; 2, 4: a tile's hidden units
+// shared by S workgroups): prepare (dynamic LDS limit) or launch.
+template <int KIND, int H, int NL, int S>
 static int mid_do(const RArgs* a, hipStream_t stream) {
   const size_t lds = sizeof(float) * (size_t)(4 * MT * PSTR + NL * MT * (H + 4) + NL * 2 * Cell<KIND>::G * H);
+  const void* fn = S == 1 ? reinterpret_cast<const void*>(&rnn_mid_kernel<KIND, H, NL>)
+                          : reinterpret_cast<const void*>(&rnn_mid_shared_kernel<KIND, H, NL, (S > 1 ? S : 2)>);
   if (!a) {
-    CET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_mid_kernel<KIND, H, NL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CET_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return CET_OK;
   }
-  hipLaunchKernelGGL((rnn_mid_kernel<KIND, H, NL>), dim3((unsigned)((a->B + MT - 1) / MT)), dim3(256), lds, stream, *a);
+  const unsigned tiles = (unsigned)((a->B + MT - 1) / MT);
+  if (S == 1)
+    hipLaunchKernelGGL((rnn_mid_kernel<KIND, H, NL>), dim3(tiles), dim3(256), lds, stream, *a);
+  else
+    hipLaunchKernelGGL((rnn_mid_shared_kernel<KIND, H, NL, (S > 1 ? S : 2)>), dim3(tiles * S), dim3(256), lds, stream, *a);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
 template <int KIND>
-static int mid_kind(const RnnModel* m, const RArgs* a, hipStream_t s) {
-#define CET_MID_CASE(H_, NL_) \
-  if (m->H == H_ && m->layers == NL_) return mid_do<KIND, H_, NL_>(a, s);
+static int mid_kind(const RnnModel* m, const RArgs* a, int S, hipStream_t s) {
+#define CET_MID_CASE(H_, NL_)                                                   \
+  if (m->H == H_ && m->layers == NL_) {                                         \
+    if (S == 4 && H_ == 256) return mid_do<KIND, H_, NL_, (H_ == 256 ? 4 : 2)>(a, s); \
+    if (S == 2) return mid_do<KIND, H_, NL_, 2>(a, s);                          \
+    if (S == 1) return mid_do<KIND, H_, NL_, 1>(a, s);                          \
+    return CET_ERR_UNSUPPORTED;                                                 \
+  }
   CET_MID_CASE(128, 1) CET_MID_CASE(128, 2) CET_MID_CASE(128, 3)
   CET_MID_CASE(256, 1) CET_MID_CASE(256, 2) CET_MID_CASE(256, 3)
 #undef CET_MID_CASE
   return CET_ERR_UNSUPPORTED;
 }
 // a == nullptr: prepare
-static int mid_dispatch(const RnnModel* m, const RArgs* a, hipStream_t s) {
+static int mid_dispatch(const RnnModel* m, const RArgs* a, int S, hipStream_t s) {
   switch (m->kind) {
-    case CET_RNN_TANH: return mid_kind<CET_RNN_TANH>(m, a, s);
-    case CET_RNN_GRU: return mid_kind<CET_RNN_GRU>(m, a, s);
-    default: return mid_kind<CET_RNN_LSTM>(m, a, s);
+    case CET_RNN_TANH: return mid_kind<CET_RNN_TANH>(m, a, S, s);
+    case CET_RNN_GRU: return mid_kind<CET_RNN_GRU>(m, a, S, s);
+    default: return mid_kind<CET_RNN_LSTM>(m, a, S, s);
   }
 }
 
@@ -1499,7 +1759,9 @@ static int rnn_prepare(const RnnModel* m) {
   PrepareFn pf;
   LaunchFn lf;
   if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
-  if (const int rc = mid_dispatch(m, nullptr, nullptr)) return rc;
+  for (int S = 1; S <= 4; S *= 2)
+    if (S == 1 || m->H / S >= 64)
+      if (const int rc = mid_dispatch(m, nullptr, S, nullptr)) return rc;
   return pf();
 }
 
@@ -1598,36 +1860,64 @@ static SplitPlan split_plan(const RnnModel* m, int tiles) {
   return {0, 1};
 }
 
-// The largest launch, and up to which batch a sequence of such launches beats the batch-tiled
-// kernel, whose time does not depend on the batch up to one tile per CU. Both times per time step
-// from a model fitted to measurements (MI355X; hidden 128 / 256, 1 to 3 layers, all three cells;
-// tools/rnnshapes.py, within 15 %):
-//   batch-tiled: 0.115 us per (k block of 8, gate, unit tile of a wave); half-tile kernel: 0.56 of that,
-//   hidden-split: 13.3 ns per MFMA a wave issues (32 cycles) + per layer 2.4 us of exchange and
-//   fixed work (2.1 us with two workgroups to a CU, 3.6 us for two tiles taking turns) + 0.6 (1.0)
-//   us per step.
+// The largest launch of the hidden-split kernel and the time estimates behind the automatic choice
+// of a kernel (rnn_choose()). Times per time step from a model fitted to measurements (MI355X;
+// hidden 128 / 256, 1 to 3 layers, all three cells; tools/rnnshapes.py, tools/midtest.py, within 15 %):
+//   batch-tiled: 0.115 us per (k block of 8, gate, unit tile of a wave), whatever the batch up to 32
+//   sequences per CU; half-tile kernel: 0.56 of that up to 16 per CU, divided by the workgroups S
+//   that share a tile, plus 1.95 us of exchange per layer and 0.6 us per step when S > 1;
+//   hidden-split, per launch: 13.3 ns per MFMA a wave issues (32 cycles) + per layer 2.4 us of
+//   exchange and fixed work (2.1 us with two workgroups to a CU, 3.6 us for two tiles taking turns)
+//   + 0.6 (1.0) us per step.
 static void rnn_split_limits(RnnModel* m) {
   int tiles = 0;
   while (tiles < 4096 && split_plan(m, tiles + 1).uw) ++tiles;
   m->split_chunk = tiles * ST;
-  m->split_max_batch = 0;
-  if (!tiles) return;
+  const int G = gates_of(m->kind), H = m->H;
+  double tiled = 0.0;
+  for (int l = 0; l < m->layers; ++l) tiled += 0.115 * (H / 128) * G * (l == 0 ? 4 + H / 8 : 2 * H / 8);
+  m->est_tiled_step = tiled;
+}
+
+// Estimated microseconds per time step of one hidden-split launch of `tiles` sequence tiles.
+static double split_step_estimate(const RnnModel* m, int tiles) {
   const SplitPlan pl = split_plan(m, tiles);
+  if (!pl.uw) return 1e30;
   const int G = gates_of(m->kind), H = m->H;
   const bool shared = split_workgroups(m, tiles, pl) > m->cus;  // two workgroups to a CU share its MFMA pipes
   const int sets = pl.uw == 16 ? G : (pl.uw == 8 ? 2 : 1);      // weight register sets per k block
-  double tiled = 0.0, split = pl.tpw == 2 ? 1.0 : 0.6;
+  double t = pl.tpw == 2 ? 1.0 : 0.6;
   for (int l = 0; l < m->layers; ++l) {
-    tiled += 0.115 * (H / 128) * G * (l == 0 ? 4 + H / 8 : 2 * H / 8);
     const int blocks = l == 0 ? 2 + H / 16 : 2 * H / 16;  // k blocks of 16, a quarter per wave
     const int mfma = (blocks + 3) / 4 * sets * 4;
-    split += (pl.tpw == 2 ? 3.6 : (shared ? 2.1 : 2.4)) + 0.0133 * mfma * (pl.tpw == 2 || shared ? 2 : 1);
+    t += (pl.tpw == 2 ? 3.6 : (shared ? 2.1 : 2.4)) + 0.0133 * mfma * (pl.tpw == 2 || shared ? 2 : 1);
   }
-  // up to one half tile per CU the half-tile kernel stands in for the batch-tiled one at 0.56 of its time
-  int chunks = (int)(0.95 * tiled / split);
-  if ((long)chunks * m->split_chunk <= (long)MT * m->cus) chunks = (int)(0.56 * tiled / split);
-  if (chunks < 1) chunks = 1;
-  m->split_max_batch = chunks * m->split_chunk;
+  return t;
+}
+
+// The kernel for a batch under the automatic choice: 1 batch-tiled, 2 hidden-split (in chunks), 4 / 5
+// / 6 half-tile with 1 / 2 / 4 workgroups per tile; the least estimated time. pooled: kernels that
+// exchange through a buffer of the pool are allowed (not under stream capture).
+static int rnn_choose(const RnnModel* m, int B, bool pooled) {
+  const long tiles = (B + MT - 1) / MT;
+  int best = 1;
+  double t_best = m->est_tiled_step * ((B + 32L * m->cus - 1) / (32L * m->cus));
+  for (int S = 1; S <= 4; S *= 2) {
+    if (tiles * S > m->cus || (S > 1 && (!pooled || !m->wstream_shared[S == 2 ? 1 : 2]))) continue;
+    if (S > 1 && (size_t)tiles * m->layers > SPLIT_CNT_SLOTS) continue;
+    const double t = 0.56 * m->est_tiled_step / S + (S > 1 ? 0.6 + 1.95 * m->layers : 0.0);
+    if (t < t_best) {
+      t_best = t;
+      best = S == 1 ? 4 : (S == 2 ? 5 : 6);
+    }
+  }
+  if (pooled && m->split_chunk > 0) {
+    const int full = B / m->split_chunk, rest = B % m->split_chunk;
+    double t = full ? full * split_step_estimate(m, m->split_chunk / ST) : 0.0;
+    if (rest) t += split_step_estimate(m, (rest + ST - 1) / ST);
+    if (t < t_best) best = 2;
+  }
+  return best;
 }
 
 // Whether the hidden-split kernel takes a batch in one launch: all its workgroups resident at once
@@ -1706,10 +1996,37 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
   return lf(t, stream);
 }
 
+// The shared half-tile rollout (S workgroups per 16-sequence tile) on `scratch`: zeroes the counters,
+// launches, and launches the batch-tiled kernel behind it on condition of the failure flag.
+static int rollout_shared(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                          int S, float* scratch, hipStream_t stream) {
+  const int si = S == 2 ? 1 : 2;
+  const long tiles = (B + MT - 1) / MT;
+  if (!m->wstream_shared[si] || tiles * S > m->cus || (size_t)tiles * m->layers > SPLIT_CNT_SLOTS)
+    return CET_ERR_TOO_LARGE;
+  RArgs a = tiled_args(m, x, out, B, seq_len, pred_len);
+  a.wstream = m->wstream_shared[si];
+  a.cnt = reinterpret_cast<unsigned*>(scratch);
+  a.hx = scratch + SPLIT_CNT_FLOATS;
+  a.spin_limit = SPIN_LIMIT;
+  CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
+  if (const int rc = mid_dispatch(m, &a, S, stream)) return rc;
+  RArgs t = tiled_args(m, x, out, B, seq_len, pred_len);
+  t.only_if = a.cnt + (SPLIT_CNT_FLOATS - 1);
+  PrepareFn pf;
+  LaunchFn lf;
+  if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
+  return lf(t, stream);
+}
+
 // Claims an exchange buffer of this device's pool for launches on `stream` (see SplitPool). The
 // caller holds pool.mu and keeps it until it has recorded the slot's event behind its launches.
 static int split_claim(const RnnModel* m, SplitPool& pool, hipStream_t stream, int* slot_out) {
-  const size_t need = (SPLIT_CNT_FLOATS + (size_t)SPLIT_MAX_OCC * m->cus * SPLIT_MAX_LAYERS * 2 * 256) * sizeof(float);
+  // hidden-split launches: up to SPLIT_MAX_OCC * CUs workgroup-slices of 256 floats per layer and parity;
+  // shared half-tile launches: up to CUs / 2 tiles of 16 x 256 floats
+  const size_t per_lp = (size_t)SPLIT_MAX_OCC * m->cus * 256 > (size_t)(m->cus / 2) * MT * 256
+                            ? (size_t)SPLIT_MAX_OCC * m->cus * 256 : (size_t)(m->cus / 2) * MT * 256;
+  const size_t need = (SPLIT_CNT_FLOATS + per_lp * SPLIT_MAX_LAYERS * 2) * sizeof(float);
   if (pool.slot_bytes < need) {  // first use on this device (the CU count of a device is fixed)
     for (int i = 0; i < SPLIT_SLOTS; ++i) {
       SplitSlot& sl = pool.slot[i];
@@ -1764,26 +2081,32 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   // batch-tiled rollout, 2 layers of 256: GRU 0.35 / 2.0 ms, LSTM 0.40 / 2.6 ms, tanh 0.18 /
   // 0.70 ms).
   const int chunk = split_chunk(m);
-  bool split = chunk > 0 && B > 0 &&
-               (m->variant == 2 || m->variant == 3 || (m->variant == 0 && B <= m->split_max_batch));
-  if (split) {
-    // Under stream capture the launches would be replayed later, outside the pool's bookkeeping:
-    // the batch-tiled kernel needs no buffer (cet_rnn_rollout_static serves captured small batches).
+  if (B <= 0) return CET_OK;
+  int kernel = m->variant;  // 1 batch-tiled, 2 / 3 hidden-split, 4 / 5 / 6 half-tile on 1 / 2 / 4 workgroups
+  if (kernel == 0) kernel = rnn_choose(m, B, true);
+  if (kernel == 2 || kernel == 3 || kernel == 5 || kernel == 6) {
+    // These exchange through a buffer of the pool. Under stream capture the launches would be
+    // replayed later, outside the pool's bookkeeping: the kernels that need no buffer serve then
+    // (cet_rnn_rollout_static serves captured small batches).
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     CET_HIP(hipStreamIsCapturing(stream, &cap));
     if (cap != hipStreamCaptureStatusNone) {
-      if (m->variant >= 2) return CET_ERR_UNSUPPORTED;
-      split = false;
+      if (m->variant != 0) return CET_ERR_UNSUPPORTED;
+      kernel = rnn_choose(m, B, false);
     }
   }
-  if (split) {
+  const bool split = (kernel == 2 || kernel == 3) && chunk > 0;
+  const int shared = kernel == 5 ? 2 : (kernel == 6 ? 4 : 0);  // workgroups per half tile
+  if ((kernel == 2 || kernel == 3) && !split) return CET_ERR_TOO_LARGE;
+  if (split || shared) {
     if (m->device < 0 || m->device >= SPLIT_MAX_DEVICES) return CET_ERR_UNSUPPORTED;
     SplitPool& pool = g_split_pool[m->device];
     std::lock_guard<std::mutex> lock(pool.mu);  // claim, launches and event as one step (see SplitPool)
     int slot = -1;
     if (const int rc = split_claim(m, pool, stream, &slot)) return rc;
     int rc = CET_OK;
-    for (int b0 = 0; b0 < B && rc == CET_OK; b0 += chunk) {
+    if (shared) rc = rollout_shared(m, x, out, B, seq_len, pred_len, shared, pool.slot[slot].buf, stream);
+    for (int b0 = 0; !shared && b0 < B && rc == CET_OK; b0 += chunk) {
       const int nb = B - b0 < chunk ? B - b0 : chunk;
       rc = !split_fits(m, nb, (long)SPLIT_MAX_OCC * m->cus)
                ? CET_ERR_TOO_LARGE
@@ -1798,9 +2121,9 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   RArgs a = tiled_args(m, x, out, B, seq_len, pred_len);
   // Up to one half tile per CU the half-tile kernel (16 sequences per workgroup) takes 0.55 of the
   // batch-tiled kernel's time; beyond, its second round of workgroups costs more than full tiles.
-  if (m->variant == 4 || (m->variant == 0 && B <= MT * m->cus)) {
+  if (kernel == 4) {
     a.wstream = m->wstream_mid;
-    return mid_dispatch(m, &a, stream);
+    return mid_dispatch(m, &a, 1, stream);
   }
 #ifdef CET_PROF
   static unsigned long long* prof_dev = nullptr;

@@ -323,7 +323,7 @@ class _RecurrentBase(_DeviceWeights):
             _cabi.check(_cabi.lib().cet_rnn_select(h, choice), "cet_rnn_select")
         return h, None
 
-    _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3, "half_tile": 4}
+    _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3, "half_tile": 4, "half_tile_2": 5, "half_tile_4": 6}
 
     def select_kernel(self, kernel):
         """Pins the rollout kernel (tests, timing): "tiled" (a workgroup takes 32 sequences and all

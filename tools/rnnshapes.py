@@ -12,7 +12,7 @@ import channelestimationtransformer_amd as cet  # noqa: E402
 from channelestimationtransformer_amd import synth  # noqa: E402
 
 dev = torch.device("cuda:0")
-sizes = [256, 512, 1024, 2048, 4096]
+sizes = [64, 256, 512, 700, 1024, 1536, 2048, 4096]
 noisy, _ = synth.channel_histories(max(sizes), seed=3)
 xall = cet.LoadBatch(noisy[:, :25]).to(dev)
 for cls in ("GRU", "LSTM", "RNN"):
