@@ -1418,7 +1418,8 @@ struct RnnModel {
   const float *w_ih[3], *w_hh[3];
   int device = 0, cus = 0;
   // 0: by batch size, 1: batch-tiled kernel, 2: hidden-split kernel, 3: hidden-split kernel whose
-  // exchange gives up at its first unanswered poll (tests: exercises the stand-by launch)
+  // exchange gives up at its first unanswered poll (tests: exercises the stand-by launch), 4 / 5 / 6:
+  // half-tile kernel with a tile's hidden units on 1 / 2 / 4 workgroups, 7: as 5, giving up like 3
   int variant = 0;
   float* static_scratch = nullptr;  // device address of g_split_scratch on this handle's device
   // workgroups of the hidden-split kernel that a CU holds at once, for 4, 8 and 16 hidden units per
@@ -2008,7 +2009,7 @@ static int rollout_shared(const RnnModel* m, const float* x, float* out, int B, 
   a.wstream = m->wstream_shared[si];
   a.cnt = reinterpret_cast<unsigned*>(scratch);
   a.hx = scratch + SPLIT_CNT_FLOATS;
-  a.spin_limit = SPIN_LIMIT;
+  a.spin_limit = m->variant == 7 ? 0 : SPIN_LIMIT;  // 7: the exchange gives up at its first unanswered poll (tests)
   CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
   if (const int rc = mid_dispatch(m, &a, S, stream)) return rc;
   RArgs t = tiled_args(m, x, out, B, seq_len, pred_len);
@@ -2084,7 +2085,7 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   if (B <= 0) return CET_OK;
   int kernel = m->variant;  // 1 batch-tiled, 2 / 3 hidden-split, 4 / 5 / 6 half-tile on 1 / 2 / 4 workgroups
   if (kernel == 0) kernel = rnn_choose(m, B, true);
-  if (kernel == 2 || kernel == 3 || kernel == 5 || kernel == 6) {
+  if (kernel == 2 || kernel == 3 || kernel >= 5) {
     // These exchange through a buffer of the pool. Under stream capture the launches would be
     // replayed later, outside the pool's bookkeeping: the kernels that need no buffer serve then
     // (cet_rnn_rollout_static serves captured small batches).
@@ -2096,7 +2097,7 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
     }
   }
   const bool split = (kernel == 2 || kernel == 3) && chunk > 0;
-  const int shared = kernel == 5 ? 2 : (kernel == 6 ? 4 : 0);  // workgroups per half tile
+  const int shared = kernel == 5 || kernel == 7 ? 2 : (kernel == 6 ? 4 : 0);  // workgroups per half tile
   if ((kernel == 2 || kernel == 3) && !split) return CET_ERR_TOO_LARGE;
   if (split || shared) {
     if (m->device < 0 || m->device >= SPLIT_MAX_DEVICES) return CET_ERR_UNSUPPORTED;

@@ -323,13 +323,15 @@ class _RecurrentBase(_DeviceWeights):
             _cabi.check(_cabi.lib().cet_rnn_select(h, choice), "cet_rnn_select")
         return h, None
 
-    _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3, "half_tile": 4, "half_tile_2": 5, "half_tile_4": 6}
+    _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3, "half_tile": 4, "half_tile_2": 5, "half_tile_4": 6,
+                "half_tile_2_giveup": 7}
 
     def select_kernel(self, kernel):
         """Pins the rollout kernel (tests, timing): "tiled" (a workgroup takes 32 sequences and all
         hidden units), "split" (small batches: 16 sequences and 4, 8 or 16 hidden units per workgroup,
         hidden states exchanged once per layer and step), "half_tile" (the tiled design with 16
-        sequences per workgroup, for batches of up to 16 per CU), "auto" (by batch size, the default) or
+        sequences per workgroup, for batches of up to 16 per CU; "half_tile_2" / "half_tile_4": a tile's
+        hidden units on 2 / 4 workgroups, for up to 8 / 4 per CU), "auto" (by estimated time, the default) or
         "split_giveup" (tests: the hidden-split kernel abandons its exchange at once, so that the
         stand-by launch of the tiled kernel behind it computes the result)."""
         self._kernel_choice = self._KERNELS[kernel]

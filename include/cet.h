@@ -151,7 +151,7 @@ int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int 
 int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len,
                     int pred_len, void* stream);
 
-/* Pins the kernel of later rollouts of this handle (tests and timing; 0..4): 0 by batch size, 1 the
+/* Pins the kernel of later rollouts of this handle (tests and timing; 0..7): 0 by batch size, 1 the
  * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
  * kernel for small batches (16 sequences and 4, 8 or 16 hidden units per workgroup - as few as
  * keeps the launch's workgroups resident at once, so that a small batch spreads over the whole
@@ -162,14 +162,17 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * few chunks), 3 the same with an exchange that gives up at its first
  * unanswered poll (tests: every chunk is then computed by the stand-by launch described next), 4
  * the half-tile kernel (the batch-tiled design with 16 sequences per workgroup: 0.55 of its time
- * up to 16 sequences per CU, which is where choice 0 uses it above the hidden-split range).
- * Rollouts on the hidden-split kernel may overlap freely, on any streams and handles and from any
+ * up to 16 sequences per CU), 5 / 6 the same with a tile's hidden units shared by 2 / 4 workgroups
+ * that exchange their states like the hidden-split kernel's (up to 8 / 4 sequences per CU; 6 needs
+ * 256 hidden units; CET_ERR_TOO_LARGE beyond), 7 as 5 with an exchange that gives up like 3. Choice
+ * 0 takes the kernel with the least estimated time for the batch.
+ * Rollouts on the kernels that exchange (2, 3, 5, 6, 7) may overlap freely, on any streams and handles and from any
  * host threads: each call claims one of four exchange buffers per GPU (a call that finds all four in flight on other
  * streams queues its stream behind one of them), and behind every hidden-split launch the
  * batch-tiled kernel is launched on the same stream on stand-by; it returns at once unless the
  * exchange gave up (other work kept part of the grid from becoming resident for about a second),
- * in which case it computes that chunk. Under stream capture choice 0 uses the batch-tiled kernel
- * and choices 2 / 3 return CET_ERR_UNSUPPORTED (cet_rnn_rollout_static serves captured small
+ * in which case it computes that chunk. Under stream capture choice 0 uses a kernel that needs no
+ * exchange and the exchanging choices return CET_ERR_UNSUPPORTED (cet_rnn_rollout_static serves captured small
  * batches). Not to be called while a rollout of the same handle runs on another thread. No
  * counterpart in the reference. */
 int cet_rnn_select(cet_handle h, int kernel);

@@ -140,6 +140,30 @@ def test_host_threads_claim_exchange_buffers_concurrently():
             assert torch.isfinite(g).all() and torch.equal(g, want[i])
 
 
+def test_shared_half_tile_rollouts_overlap_and_fall_back():
+    """The half-tile kernels whose workgroups share a tile exchange through the same pool of buffers:
+    rollouts of one handle on three streams at once reproduce the single-stream bits, and an
+    exchange that gives up at its first unanswered poll is recomputed by the stand-by launch."""
+    gru = build_rnn("GRU", "half_tile_2")
+    xs = [_histories(B, 40 + B) for B in (700, 1000, 1500)]
+    kinds = ["half_tile_4", "half_tile_2", "half_tile_2"]
+    want = [gru.select_kernel(k).test_data(x, 5, "cuda") for k, x in zip(kinds, xs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in xs]
+    got = [[] for _ in xs]
+    for _ in range(6):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                got[i].append(gru.select_kernel(kinds[i]).test_data(xs[i], 5, "cuda"))
+    torch.cuda.synchronize()
+    for i in range(len(xs)):
+        for g in got[i]:
+            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+    tiled = gru.select_kernel("tiled").test_data(xs[0], 5, "cuda")
+    rescued = gru.select_kernel("half_tile_2_giveup").test_data(xs[0], 5, "cuda")
+    assert torch.equal(rescued, tiled)
+
+
 @pytest.mark.parametrize("name", ["GRU", "LSTM", "RNN"])
 def test_abandoned_exchange_is_recomputed_by_the_stand_by_launch(name):
     """"split_giveup" makes the hidden-split kernel abandon its exchange at the first unanswered
