@@ -749,15 +749,17 @@ def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
         lat[f"{kind}_pred5_ms"] = d64g * 1e3
         lat[f"{kind}_predictions_per_s"] = 64 / d64g
     extra["batch_64_latency"] = lat
-    # medium batches of the recurrent predictors (the hidden-split kernel in chunks of 256 sequences)
-    x1k = x[:1024].contiguous()
-    mid = {}
-    for kind in ("gru", "lstm", "rnn"):
-        gm, _sd = make_rnn(kind)
-        d1k = timed_steady(lambda: gm.test_data(x1k, 5, dev), dev)
-        mid[f"{kind}_pred5_ms"] = d1k * 1e3
-        mid[f"{kind}_predictions_per_s"] = 1024 / d1k
-    extra["batch_1024_rollout"] = mid
+    # medium batches of the recurrent predictors (the kernel the library picks for the batch: half-tile
+    # workgroups of 16 sequences, a tile's hidden units on 4 / 2 / 1 workgroups at 1024 / 2048 / 4096)
+    for nb in (1024, 2048, 4096):
+        xm = x[:nb].contiguous()
+        mid = {}
+        for kind in ("gru", "lstm", "rnn"):
+            gm, _sd = make_rnn(kind)
+            dm = timed_steady(lambda: gm.test_data(xm, 5, dev), dev)
+            mid[f"{kind}_pred5_ms"] = dm * 1e3
+            mid[f"{kind}_predictions_per_s"] = nb / dm
+        extra[f"batch_{nb}_rollout"] = mid
 
     # ---- recurrent rollouts, 8192 sequences, pred_len 5 / 25 / 100 ------------------------------
     for kind in ("lstm", "gru", "rnn"):
