@@ -1264,7 +1264,49 @@ __global__ __launch_bounds__(256) void rnn_mid_shared_kernel(const RArgs a) {
   unsigned* const fail = a.cnt + (SPLIT_CNT_FLOATS - 1);
   __syncthreads();
 
+  // Waits until all S workgroups of the tile have published layer l of step t (and, with l2 >= 0,
+  // layer l2 of step t2), then copies the full state(s) into LDS.
+  auto fetch = [&](const int l, const int t, const int l2 = -1, const int t2 = 0) __attribute__((always_inline)) {
+    if (tid == 0 && !dead) {
+      const unsigned target = (unsigned)S * (unsigned)(t + 1), target2 = (unsigned)S * (unsigned)(t2 + 1);
+      int spins = 0;
+      while (__hip_atomic_load(cnt_tile + l * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target ||
+             (l2 >= 0 &&
+              __hip_atomic_load(cnt_tile + l2 * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target2)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > a.spin_limit) {
+          dead = 1;
+          __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    // a layer's full state: H MT / 4 pieces of 16 bytes, thread tid takes pieces tid + 256 r
+    constexpr int NPC = H * MT / 4 / 256;
+    const unsigned so = (unsigned)((l * 2 + (t & 1)) * H * MT) * 4u;
+    const unsigned so2 = (unsigned)(((l2 >= 0 ? l2 : 0) * 2 + (t2 & 1)) * H * MT) * 4u;
+    u32x4 v[NPC], v2[NPC];
+#pragma unroll
+    for (int r = 0; r < NPC; ++r)
+      v[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, (unsigned)(tid + 256 * r) * 16u, so, AGENT_SCOPE);
+    if (l2 >= 0) {
+#pragma unroll
+      for (int r = 0; r < NPC; ++r)
+        v2[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, (unsigned)(tid + 256 * r) * 16u, so2, AGENT_SCOPE);
+    }
+#pragma unroll
+    for (int r = 0; r < NPC; ++r) {
+      const int p = tid + 256 * r;
+      st4(hbuf + l * MT * HS + (p / (H / 4)) * HS + 4 * (p % (H / 4)), __builtin_bit_cast(f32x4, v[r]));
+      if (l2 >= 0)
+        st4(hbuf + l2 * MT * HS + (p / (H / 4)) * HS + 4 * (p % (H / 4)), __builtin_bit_cast(f32x4, v2[r]));
+    }
+    __syncthreads();
+  };
+
   const int n_steps = a.seq_len + a.pred_len - 1;
+  bool pending_top = false;
   for (int idx = 0; idx < n_steps; ++idx) {
     f32x4 xnext[XB];
 #pragma unroll
@@ -1324,35 +1366,20 @@ __global__ __launch_bounds__(256) void rnn_mid_shared_kernel(const RArgs a) {
                                                (unsigned)(c * H + unit_w + 16 * u + 4 * g) * 4u, so, AGENT_SCOPE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier the arrival follows
       __syncthreads();  // ... which also says that every wave has finished reading the old h of this layer
-      if (tid == 0) {
+      if (tid == 0)
         __hip_atomic_fetch_add(cnt_tile + l * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!dead) {
-          const unsigned target = (unsigned)S * (unsigned)(idx + 1);
-          int spins = 0;
-          while (__hip_atomic_load(cnt_tile + l * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > a.spin_limit) {
-              dead = 1;
-              __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
-          }
-        }
+      // The top layer's state is needed by the decoder (closed-loop steps) or by the next step's top
+      // layer: in a teacher-forced step its wait is put off behind the next step's lower layers and
+      // shares their round trip (as in the hidden-split kernel).
+      if (l < NL - 1) {
+        if (l == NL - 2 && pending_top) fetch(l, idx, NL - 1, idx - 1);
+        else fetch(l, idx);
+        if (l == NL - 2) pending_top = false;
+      } else if (decode || NL == 1) {
+        fetch(NL - 1, idx);
+      } else {
+        pending_top = true;
       }
-      __syncthreads();
-      {  // the layer's full state: H MT / 4 pieces of 16 bytes, thread tid takes pieces tid + 256 r
-        constexpr int NPC = H * MT / 4 / 256;
-        u32x4 v[NPC];
-#pragma unroll
-        for (int r = 0; r < NPC; ++r)
-          v[r] = __builtin_amdgcn_raw_buffer_load_b128(hx_rsrc, (unsigned)(tid + 256 * r) * 16u, so, AGENT_SCOPE);
-#pragma unroll
-        for (int r = 0; r < NPC; ++r) {
-          const int p = tid + 256 * r;
-          st4(hl + (p / (H / 4)) * HS + 4 * (p % (H / 4)), __builtin_bit_cast(f32x4, v[r]));
-        }
-      }
-      __syncthreads();
     }
 
     // ---- decoder Linear on the new top hidden state: the prediction and the next input ----
