@@ -417,7 +417,10 @@ def run_rnn(ctx, kind, B, P, steps, warmup, cpu_baseline=False):
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": measured_traffic(kind, B) if P == 5 else None,  # profiled at pred_len 5
-                     "kernel": "rnn_rollout_kernel", "kernel_ms": dev_s * 1e3, "flop_per_launch": flop},
+                     # the library's choice for the batch at 256 hidden units on 256 CUs
+                     "kernel": ("rnn_rollout_kernel" if B > 4096 else "rnn_mid_kernel" if B > 2048 else
+                                "rnn_mid_shared_kernel" if B > 512 else "rnn_split_kernel"),
+                     "kernel_ms": dev_s * 1e3, "flop_per_launch": flop},
     }
     out["nmse_check"] = rnn_nmse_check(kind, dev)
     if cpu_baseline:

@@ -32,6 +32,15 @@ for w in informer informer_nomaps informer12 lstm gru rnn lmmse lmmse_block; do
   done
   echo "profiled $w"
 done
+# the medium-batch recurrent kernels: kernel trace and the MFMA pass
+WL[gru_b4096]="--workload gru --pred-len 5 --batch 4096"
+WL[gru_b2048]="--workload gru --pred-len 5 --batch 2048"
+WL[gru_b1024]="--workload gru --pred-len 5 --batch 1024"
+for w in gru_b4096 gru_b2048 gru_b1024; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $REPO/bench.py --steps 200 --warmup 50 --skip-cpu-baseline --skip-secondary ${WL[$w]} > $OUT/trace_$w.log 2>&1 || { tail -5 $OUT/trace_$w.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $PASS_A --output-format csv -d $OUT/pmc_${w}_A -- python3 $REPO/bench.py --steps 3 --warmup 1 --skip-cpu-baseline --skip-secondary ${WL[$w]} > $OUT/pmc_${w}_A.log 2>&1 || { tail -5 $OUT/pmc_${w}_A.log; exit 1; }
+  echo "profiled $w"
+done
 for c in FETCH_SIZE WRITE_SIZE; do
   for w in informer informer_nomaps informer12 lstm lmmse lmmse_block; do
     timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${w}_$c -- python3 $REPO/bench.py --steps 3 --warmup 1 --skip-cpu-baseline --skip-secondary ${WL[$w]} > $OUT/pmc_${w}_$c.log 2>&1 || { tail -5 $OUT/pmc_${w}_$c.log; exit 1; }

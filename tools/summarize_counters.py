@@ -28,6 +28,11 @@ WORKLOADS = {
     "lstm": ("rnn_rollout_kernel", "--workload lstm --pred-len 5 (B=8192)", 8192, 25 * 16 * 4 + 5 * 16 * 4),
     "gru": ("rnn_rollout_kernel", "--workload gru --pred-len 5 (B=8192)", 8192, 25 * 16 * 4 + 5 * 16 * 4),
     "rnn": ("rnn_rollout_kernel", "--workload rnn --pred-len 5 (B=8192)", 8192, 25 * 16 * 4 + 5 * 16 * 4),
+    "gru_b4096": ("rnn_mid_kernel", "--workload gru --pred-len 5 --batch 4096 (half tiles)", 4096, 25 * 16 * 4 + 5 * 16 * 4),
+    "gru_b2048": ("rnn_mid_shared_kernel", "--workload gru --pred-len 5 --batch 2048 (half tiles on 2 workgroups)", 2048,
+                  25 * 16 * 4 + 5 * 16 * 4),
+    "gru_b1024": ("rnn_mid_shared_kernel", "--workload gru --pred-len 5 --batch 1024 (half tiles on 4 workgroups)", 1024,
+                  25 * 16 * 4 + 5 * 16 * 4),
     "lmmse": ("lmmse_tiled", "--workload lmmse --batch 8388608 (16x4)", 8388608, 688),
     "lmmse_block": ("lmmse_block", "--workload lmmse --batch 8388608 --h-share 14", 8388608, 688 - 512 * 13 / 14),
 }
