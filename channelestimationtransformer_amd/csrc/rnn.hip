@@ -974,7 +974,8 @@ __global__ __launch_bounds__(256, (UW < 16 && TPW == 1) ? 2 : 1) void rnn_split_
 // operand; the decoder Linear takes the fresh h from registers. A workgroup issues half the MFMAs
 // per step and streams the same weights, so it needs twice the L2 bandwidth per CU (32 B / clock).
 constexpr int MT = 16;  // sequences per workgroup
-constexpr int mid_ring_depth(int kind, int H) { return kind == CET_RNN_TANH && H >= 256 ? 16 : 8; }
+// (a divisor of H / 16: 16 for the tanh cell from 256 hidden units on, else 8, 4 at 64 hidden units)
+constexpr int mid_ring_depth(int kind, int H) { return H < 128 ? 4 : (kind == CET_RNN_TANH && H >= 256 ? 16 : 8); }
 
 template <int KIND, bool PART_H>
 DEV void kblock16(f32x4 (&acc)[Cell<KIND>::NACC], const f32x4 (&wt)[Cell<KIND>::G], const f32x4 bf) {
@@ -1437,6 +1438,7 @@ static __device__ __align__(256) float g_split_scratch[SPLIT_MAX_FLOATS];
 
 struct RnnModel {
   int kind, F, I, H, layers;
+  bool core = true;      // rnn_core_shape(): every kernel serves it, else the half-tile kernel alone
   float* dev = nullptr;  // one allocation; the pointers below point into it
   // bias: SArgs::bias (hidden-split kernel); bias_tiled: RArgs::bias
   const float *wstream, *wstream_mid, *bias, *bias_tiled, *dec_w, *dec_b;
@@ -1489,10 +1491,13 @@ static void rnn_split_limits(RnnModel* m);    // fills split_chunk from split_oc
 
 static int gates_of(int kind) { return kind == CET_RNN_TANH ? 1 : (kind == CET_RNN_GRU ? 3 : 4); }
 
+// Every kernel serves hidden 128 / 256 with up to 3 layers ("core" shapes); hidden 64 / 512 and 4
+// layers run on the half-tile kernel alone, whatever the batch.
+static bool rnn_core_shape(int H, int layers) { return (H == 128 || H == 256) && layers <= 3; }
 static bool rnn_supported(int kind, int F, int I, int H, int layers) {
   if (kind < CET_RNN_TANH || kind > CET_RNN_LSTM) return false;
-  if (H != 128 && H != 256) return false;
-  if (layers < 1 || layers > 3) return false;
+  if (H != 64 && H != 128 && H != 256 && H != 512) return false;
+  if (layers < 1 || layers > (H == 512 ? 3 : 4)) return false;  // 512 x 4 layers: the h buffers exceed the LDS
   if (F < 4 || F > FP || F % 4) return false;
   if (I < 1 || I > 4096) return false;  // folded into the first layer at create time: any width
   return true;
@@ -1524,8 +1529,9 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   const float* p = w;
   const float* enc_w = p; p += (size_t)I * F;
   const float* enc_b = p; p += I;
+  const bool core = rnn_core_shape(H, layers);
   const int D = ring_depth(kind);
-  if (D < 4 || (H / 8) % D) return CET_ERR_UNSUPPORTED;  // up to 4 k-blocks of features in a segment of D
+  if (core && (D < 4 || (H / 8) % D)) return CET_ERR_UNSUPPORTED;  // up to 4 k-blocks of features in a segment of D
   struct LayerW { const float *w_ih, *w_hh; int in; };
   std::vector<LayerW> lw;
   std::vector<float> stream, bias, bias_tiled;
@@ -1563,7 +1569,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   // one stream per wave in consumption order: [layer][unit tile][input segment | hidden segment]
   // [k-block][gate][64 lanes][4]; the layer-0 input segment is padded to D k-blocks
-  for (int wave = 0; wave < 4; ++wave)
+  for (int wave = 0; core && wave < 4; ++wave)
     for (int l = 0; l < layers; ++l)
       for (int u = 0; u < UT; ++u)
         for (int part = 0; part < 2; ++part) {
@@ -1603,7 +1609,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   // ... and for its shared form, one stream per (share of the units, wave): [share][wave][layer]...
   std::vector<float> stream_shared[3];
-  for (int si = 1; si < 3; ++si) {
+  for (int si = 1; core && si < 3; ++si) {
     const int S = 1 << si;
     if (H / S < 64) continue;  // a wave takes at least one tile of 16 units
     const int DM_ = mid_ring_depth(kind, H), UTW = H / S / 64;
@@ -1637,7 +1643,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
 
   RnnModel* m = new (std::nothrow) RnnModel;
   if (!m) return CET_ERR_ALLOC;
-  m->kind = kind; m->F = F; m->I = I; m->H = H; m->layers = layers;
+  m->kind = kind; m->F = F; m->I = I; m->H = H; m->layers = layers; m->core = core;
   std::vector<float> all;
   auto place = [&](const std::vector<float>& v) {
     const size_t off = all.size();
@@ -1652,7 +1658,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   for (int si = 1; si < 3; ++si)
     if (!stream_shared[si].empty()) o_shared[si] = place(stream_shared[si]);
   size_t o_ih[3] = {0, 0, 0}, o_hh[3] = {0, 0, 0};
-  for (int l = 0; l < layers; ++l) {
+  for (int l = 0; core && l < layers; ++l) {
     o_ih[l] = place(l == 0 ? w_fold : std::vector<float>(lw[l].w_ih, lw[l].w_ih + (size_t)G * H * lw[l].in));
     o_hh[l] = place(std::vector<float>(lw[l].w_hh, lw[l].w_hh + (size_t)G * H * H));
   }
@@ -1670,7 +1676,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     m->wstream_shared[si] = stream_shared[si].empty() ? nullptr : m->dev + o_shared[si];
   m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
   for (int l = 0; l < 3; ++l) {
-    m->w_ih[l] = l < layers ? m->dev + o_ih[l] : nullptr;
+    m->w_ih[l] = core && l < layers ? m->dev + o_ih[l] : nullptr;
     m->w_hh[l] = l < layers ? m->dev + o_hh[l] : nullptr;
   }
   e = hipGetDevice(&m->device);
@@ -1681,8 +1687,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
     return hip_fail(e);
   }
   int rc = rnn_prepare(m);
-  if (rc == CET_OK) rc = rnn_split_occupancy(m);
-  if (rc == CET_OK) rnn_split_limits(m);
+  if (rc == CET_OK && core) rc = rnn_split_occupancy(m);
+  if (rc == CET_OK && core) rnn_split_limits(m);
   if (rc != CET_OK) {
     rnn_destroy(m);
     return rc;
@@ -1746,17 +1752,19 @@ static bool variant(int kind, int ut, int layers, PrepareFn* pf, LaunchFn* lf) {
 template <int KIND, int H, int NL, int S>
 static int mid_do(const RArgs* a, hipStream_t stream) {
   const size_t lds = sizeof(float) * (size_t)(4 * MT * PSTR + NL * MT * (H + 4) + NL * 2 * Cell<KIND>::G * H);
-  const void* fn = S == 1 ? reinterpret_cast<const void*>(&rnn_mid_kernel<KIND, H, NL>)
-                          : reinterpret_cast<const void*>(&rnn_mid_shared_kernel<KIND, H, NL, (S > 1 ? S : 2)>);
+  const void* fn;
+  if constexpr (S == 1) fn = reinterpret_cast<const void*>(&rnn_mid_kernel<KIND, H, NL>);
+  else fn = reinterpret_cast<const void*>(&rnn_mid_shared_kernel<KIND, H, NL, S>);
   if (!a) {
+    if (lds > 160 * 1024 - 64) return CET_ERR_UNSUPPORTED;
     CET_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return CET_OK;
   }
   const unsigned tiles = (unsigned)((a->B + MT - 1) / MT);
-  if (S == 1)
+  if constexpr (S == 1)
     hipLaunchKernelGGL((rnn_mid_kernel<KIND, H, NL>), dim3(tiles), dim3(256), lds, stream, *a);
   else
-    hipLaunchKernelGGL((rnn_mid_shared_kernel<KIND, H, NL, (S > 1 ? S : 2)>), dim3(tiles * S), dim3(256), lds, stream, *a);
+    hipLaunchKernelGGL((rnn_mid_shared_kernel<KIND, H, NL, S>), dim3(tiles * S), dim3(256), lds, stream, *a);
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
@@ -1772,6 +1780,13 @@ static int mid_kind(const RnnModel* m, const RArgs* a, int S, hipStream_t s) {
   CET_MID_CASE(128, 1) CET_MID_CASE(128, 2) CET_MID_CASE(128, 3)
   CET_MID_CASE(256, 1) CET_MID_CASE(256, 2) CET_MID_CASE(256, 3)
 #undef CET_MID_CASE
+  // the other shapes: a tile per workgroup only
+#define CET_MID_ONLY(H_, NL_) \
+  if (m->H == H_ && m->layers == NL_) return S == 1 ? mid_do<KIND, H_, NL_, 1>(a, s) : CET_ERR_UNSUPPORTED;
+  CET_MID_ONLY(64, 1) CET_MID_ONLY(64, 2) CET_MID_ONLY(64, 3) CET_MID_ONLY(64, 4)
+  CET_MID_ONLY(128, 4) CET_MID_ONLY(256, 4)
+  CET_MID_ONLY(512, 1) CET_MID_ONLY(512, 2) CET_MID_ONLY(512, 3)
+#undef CET_MID_ONLY
   return CET_ERR_UNSUPPORTED;
 }
 // a == nullptr: prepare
@@ -1784,6 +1799,7 @@ static int mid_dispatch(const RnnModel* m, const RArgs* a, int S, hipStream_t s)
 }
 
 static int rnn_prepare(const RnnModel* m) {
+  if (!m->core) return mid_dispatch(m, nullptr, 1, nullptr);
   PrepareFn pf;
   LaunchFn lf;
   if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
@@ -2091,6 +2107,7 @@ void rnn_select(RnnModel* m, int variant) { m->variant = variant; }
 // The rollout on the library's static scratch buffer: no allocation on any path.
 int rnn_rollout_static(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                        hipStream_t stream) {
+  if (!m->core) return CET_ERR_UNSUPPORTED;  // no hidden-split kernel for this shape
   if (!split_fits(m, B, SPLIT_MAX_WG) || m->layers > SPLIT_MAX_LAYERS) return CET_ERR_TOO_LARGE;
   return rollout_split(m, x, out, B, seq_len, pred_len, m->static_scratch, stream);
 }
@@ -2111,6 +2128,10 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   const int chunk = split_chunk(m);
   if (B <= 0) return CET_OK;
   int kernel = m->variant;  // 1 batch-tiled, 2 / 3 hidden-split, 4 / 5 / 6 half-tile on 1 / 2 / 4 workgroups
+  if (!m->core) {  // hidden 64 / 512 or 4 layers: the half-tile kernel, in as many rounds of workgroups as it takes
+    if (kernel != 0 && kernel != 4) return CET_ERR_UNSUPPORTED;
+    kernel = 4;
+  }
   if (kernel == 0) kernel = rnn_choose(m, B, true);
   if (kernel == 2 || kernel == 3 || kernel >= 5) {
     // These exchange through a buffer of the pool. Under stream capture the launches would be

@@ -139,8 +139,11 @@ size_t cet_rnn_blob_size(int kind, int features, int input_size, int hidden_size
 /* Stands in for `GRU/LSTM/RNN(features, input_size, hidden_size, num_layers)` +
  * `load_state_dict` + `.eval()` (LocalSimulations/models/model.py:276, 350, 426;
  * HPC/python/Evaluate.py:60-98). `weights` is a HOST pointer. Supported: features a multiple of
- * 4 up to 32, hidden_size 128 or 256, 1 to 3 layers, input_size 1 to 4096 (the encoder Linear is
- * folded into the first layer's input weights at create time, in double precision). */
+ * 4 up to 32, hidden_size 64, 128, 256 or 512, 1 to 4 layers (3 at 512), input_size 1 to 4096
+ * (the encoder Linear is folded into the first layer's input weights at create time, in double
+ * precision). Hidden 128 / 256 with up to 3 layers are served by every kernel of cet_rnn_select;
+ * the other shapes by the half-tile kernel alone, at every batch size (choices 0 and 4; the
+ * others and cet_rnn_rollout_static return CET_ERR_UNSUPPORTED). */
 int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int num_layers,
                    const float* weights, size_t n_weights, cet_handle* out);
 

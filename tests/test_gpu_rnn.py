@@ -168,6 +168,34 @@ def test_random_shapes_against_checker(cls, F, I, H, layers, variant, oracle):
     assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
 
 
+OTHER_SHAPES = [(cls, F, I, H, layers) for cls in ("RNN", "GRU", "LSTM")
+                for (F, I, H, layers) in ((16, 32, 64, 2), (16, 16, 512, 2), (32, 48, 256, 4), (8, 8, 64, 4),
+                                           (16, 32, 512, 3), (16, 32, 128, 4), (16, 32, 512, 1))]
+
+
+@pytest.mark.parametrize("cls,F,I,H,layers", OTHER_SHAPES)
+def test_hidden_64_and_512_and_four_layers(cls, F, I, H, layers, oracle):
+    """Shapes beyond hidden 128 / 256 and three layers run on the half-tile kernel at every batch size
+    (LocalSimulations/models/model.py:276, 350, 426 take any): a small ragged batch and one of several
+    rounds of workgroups against the CPU checker; the kernels that do not serve the shape refuse it."""
+    kind = {"RNN": 0, "GRU": 1, "LSTM": 2}[cls]
+    torch.manual_seed(F + I + H + layers + kind)
+    m = getattr(cet, cls)(F, I, H, layers).eval()
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(H + layers)
+    x = rng.standard_normal((4200, 8, F)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    out = m.test_data(xd, 6, "cuda")
+    assert out.shape == (4200, 6, F) and torch.isfinite(out).all()
+    assert torch.equal(m.select_kernel("half_tile").test_data(xd[:37].contiguous(), 6, "cuda"), out[:37])
+    idx = np.r_[0:40, 4180:4200]
+    want = oracle.rnn_rollout(kind, F, I, H, layers, blobs.pack_rnn(sd, kind, F, I, H, layers), x[idx], 6)
+    assert np.abs(out.cpu().numpy()[idx] - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
+    for variant in ("tiled", "split", "half_tile_2"):
+        with pytest.raises(RuntimeError):
+            m.select_kernel(variant).test_data(xd[:37].contiguous(), 6, "cuda")
+
+
 @pytest.mark.parametrize("name", sorted(RNN_CASES))
 def test_parameter_update_then_rollout(name, oracle):
     """Parameters changed while the module is in training mode (what a training loop of the
@@ -274,3 +302,21 @@ def test_literal_4x4_mimo_configuration(cell, variant):
         out = m.test_data(x, P, "cuda").cpu().numpy()
         assert out.shape == want.shape == (64, P, 32)
         assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("cell", ["GRU", "LSTM", "RNN"])
+def test_other_shapes_against_the_imported_reference(cell):
+    """GRU(16, 32, 512, 1), LSTM(16, 16, 64, 4), RNN(16, 32, 256, 4) on 48 histories, pred_len 5,
+    against the imported reference (tests/golden/make_golden_shapes.py;
+    LocalSimulations/models/model.py:298-312, 373-388, 449-465). Weights: PyTorch's default
+    initialisation (no checkpoint of these shapes ships with the reference)."""
+    v = load_npz("rnn_shapes.npz")
+    shape = tuple(int(n) for n in v[f"{cell}/shape"])
+    m = getattr(cet, cell)(*shape)
+    m.load_state_dict({k: torch.from_numpy(np.array(a)) for k, a in sub_dict(v, f"{cell}/sd").items()})
+    m.eval()
+    x = torch.from_numpy(v["x"]).cuda()
+    want = v[f"{cell}/pred5"]
+    out = m.test_data(x, 5, "cuda").cpu().numpy()
+    assert out.shape == want.shape == (48, 5, 16)
+    assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
