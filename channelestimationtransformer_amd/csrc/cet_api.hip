@@ -191,7 +191,7 @@ int cet_rnn_rollout_static(cet_handle h, const float* x, float* out, int B, int 
 }
 
 int cet_rnn_select(cet_handle h, int kernel) {
-  if (!h || h->kind != HANDLE_RNN || kernel < 0 || kernel > 7) return CET_ERR_INVALID_ARG;
+  if (!h || h->kind != HANDLE_RNN || kernel < 0 || kernel > 8) return CET_ERR_INVALID_ARG;
   rnn_select(static_cast<RnnModel*>(h->impl), kernel);
   return CET_OK;
 }

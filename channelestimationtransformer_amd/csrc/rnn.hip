@@ -460,8 +460,8 @@ constexpr int ST = 16;        // sequences per workgroup
 // 512-byte block every poll and every arrival of the whole grid went to one memory channel), and in
 // the last word the grid's failure flag.
 constexpr int CNT_STRIDE = 32;                 // words between counters
-constexpr size_t SPLIT_CNT_SLOTS = 511;        // counters the header has room for
-constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 64 KiB
+constexpr size_t SPLIT_CNT_SLOTS = 767;        // counters the header has room for
+constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 96 KiB
 constexpr int SPIN_LIMIT = 1 << 20;  // polls of about a microsecond each: a second or two
 
 DEV f32x4 mfma16(float a, float b, f32x4 c) {
@@ -974,6 +974,8 @@ __global__ __launch_bounds__(256, (UW < 16 && TPW == 1) ? 2 : 1) void rnn_split_
 // operand; the decoder Linear takes the fresh h from registers. A workgroup issues half the MFMAs
 // per step and streams the same weights, so it needs twice the L2 bandwidth per CU (32 B / clock).
 constexpr int MT = 16;  // sequences per workgroup
+// A tile's hidden units go on S workgroups only while each keeps a unit tile of 16 per wave.
+static bool mid_share_ok(int H, int S) { return S == 1 || (H / S >= 64 && S <= 8); }
 // (a divisor of H / 16: 16 for the tanh cell from 256 hidden units on, else 8, 4 at 64 hidden units)
 constexpr int mid_ring_depth(int kind, int H) { return H < 128 ? 4 : (kind == CET_RNN_TANH && H >= 256 ? 16 : 8); }
 
@@ -1426,7 +1428,7 @@ constexpr int SPLIT_MAX_WG = 256;    // workgroups the static buffer below serve
 constexpr int SPLIT_MAX_LAYERS = 3;
 constexpr size_t SPLIT_MAX_FLOATS = SPLIT_CNT_FLOATS + (size_t)SPLIT_MAX_WG * SPLIT_MAX_LAYERS * 2 * 256;
 
-// The buffer of the entry point that allocates nothing (cet_rnn_rollout_static): 1.5 MiB per GPU
+// The buffer of the entry point that allocates nothing (cet_rnn_rollout_static): 1.6 MiB per GPU
 // the library runs on, held until the process ends. Host code never uses this name as an
 // address; rnn_create() asks the runtime for the device address once per handle.
 static __device__ __align__(256) float g_split_scratch[SPLIT_MAX_FLOATS];
@@ -1442,7 +1444,7 @@ struct RnnModel {
   float* dev = nullptr;  // one allocation; the pointers below point into it
   // bias: SArgs::bias (hidden-split kernel); bias_tiled: RArgs::bias
   const float *wstream, *wstream_mid, *bias, *bias_tiled, *dec_w, *dec_b;
-  const float* wstream_shared[3] = {nullptr, nullptr, nullptr};  // shared half-tile kernel, S = 2 and 4 at [1], [2]
+  const float* wstream_shared[4] = {nullptr, nullptr, nullptr, nullptr};  // shared half-tile kernel, S = 2, 4, 8 at [1], [2], [3]
   // gate weights in their PyTorch layouts (hidden-split kernel); w_ih[0] with the encoder folded in
   const float *w_ih[3], *w_hh[3];
   int device = 0, cus = 0;
@@ -1608,10 +1610,10 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
           }
   }
   // ... and for its shared form, one stream per (share of the units, wave): [share][wave][layer]...
-  std::vector<float> stream_shared[3];
-  for (int si = 1; core && si < 3; ++si) {
+  std::vector<float> stream_shared[4];
+  for (int si = 1; si < 4; ++si) {
     const int S = 1 << si;
-    if (H / S < 64) continue;  // a wave takes at least one tile of 16 units
+    if (!mid_share_ok(H, S)) continue;
     const int DM_ = mid_ring_depth(kind, H), UTW = H / S / 64;
     for (int sh = 0; sh < S; ++sh)
       for (int wave = 0; wave < 4; ++wave)
@@ -1654,8 +1656,8 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   const size_t o_stream = place(stream), o_stream_mid = place(stream_mid), o_bias = place(bias),
                o_bias_t = place(bias_tiled),
                o_dw = place(dw), o_db = place(db);
-  size_t o_shared[3] = {0, 0, 0};
-  for (int si = 1; si < 3; ++si)
+  size_t o_shared[4] = {0, 0, 0, 0};
+  for (int si = 1; si < 4; ++si)
     if (!stream_shared[si].empty()) o_shared[si] = place(stream_shared[si]);
   size_t o_ih[3] = {0, 0, 0}, o_hh[3] = {0, 0, 0};
   for (int l = 0; core && l < layers; ++l) {
@@ -1672,7 +1674,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   m->wstream = m->dev + o_stream; m->wstream_mid = m->dev + o_stream_mid; m->bias = m->dev + o_bias;
   m->bias_tiled = m->dev + o_bias_t;
-  for (int si = 1; si < 3; ++si)
+  for (int si = 1; si < 4; ++si)
     m->wstream_shared[si] = stream_shared[si].empty() ? nullptr : m->dev + o_shared[si];
   m->dec_w = m->dev + o_dw; m->dec_b = m->dev + o_db;
   for (int l = 0; l < 3; ++l) {
@@ -1688,7 +1690,7 @@ int rnn_create(int kind, int F, int I, int H, int layers, const float* w, size_t
   }
   int rc = rnn_prepare(m);
   if (rc == CET_OK && core) rc = rnn_split_occupancy(m);
-  if (rc == CET_OK && core) rnn_split_limits(m);
+  if (rc == CET_OK) rnn_split_limits(m);
   if (rc != CET_OK) {
     rnn_destroy(m);
     return rc;
@@ -1768,25 +1770,24 @@ static int mid_do(const RArgs* a, hipStream_t stream) {
   CET_HIP(hipGetLastError());
   return CET_OK;
 }
+// Workgroups a tile's hidden units may be shared by: a wave takes at least one tile of 16 units
+// (S <= H / 64), at most 4 at 256 hidden units and 8 at 512.
 template <int KIND>
 static int mid_kind(const RnnModel* m, const RArgs* a, int S, hipStream_t s) {
-#define CET_MID_CASE(H_, NL_)                                                   \
-  if (m->H == H_ && m->layers == NL_) {                                         \
-    if (S == 4 && H_ == 256) return mid_do<KIND, H_, NL_, (H_ == 256 ? 4 : 2)>(a, s); \
-    if (S == 2) return mid_do<KIND, H_, NL_, 2>(a, s);                          \
-    if (S == 1) return mid_do<KIND, H_, NL_, 1>(a, s);                          \
-    return CET_ERR_UNSUPPORTED;                                                 \
+#define CET_MID_S(H_, NL_, S_) \
+  if (S == S_) return mid_do<KIND, H_, NL_, (H_ / S_ >= 64 ? S_ : 1)>(a, s);
+#define CET_MID_CASE(H_, NL_)                         \
+  if (m->H == H_ && m->layers == NL_) {               \
+    if (!mid_share_ok(H_, S)) return CET_ERR_UNSUPPORTED; \
+    CET_MID_S(H_, NL_, 1) CET_MID_S(H_, NL_, 2) CET_MID_S(H_, NL_, 4) CET_MID_S(H_, NL_, 8) \
+    return CET_ERR_UNSUPPORTED;                       \
   }
-  CET_MID_CASE(128, 1) CET_MID_CASE(128, 2) CET_MID_CASE(128, 3)
-  CET_MID_CASE(256, 1) CET_MID_CASE(256, 2) CET_MID_CASE(256, 3)
+  CET_MID_CASE(64, 1) CET_MID_CASE(64, 2) CET_MID_CASE(64, 3) CET_MID_CASE(64, 4)
+  CET_MID_CASE(128, 1) CET_MID_CASE(128, 2) CET_MID_CASE(128, 3) CET_MID_CASE(128, 4)
+  CET_MID_CASE(256, 1) CET_MID_CASE(256, 2) CET_MID_CASE(256, 3) CET_MID_CASE(256, 4)
+  CET_MID_CASE(512, 1) CET_MID_CASE(512, 2) CET_MID_CASE(512, 3)
 #undef CET_MID_CASE
-  // the other shapes: a tile per workgroup only
-#define CET_MID_ONLY(H_, NL_) \
-  if (m->H == H_ && m->layers == NL_) return S == 1 ? mid_do<KIND, H_, NL_, 1>(a, s) : CET_ERR_UNSUPPORTED;
-  CET_MID_ONLY(64, 1) CET_MID_ONLY(64, 2) CET_MID_ONLY(64, 3) CET_MID_ONLY(64, 4)
-  CET_MID_ONLY(128, 4) CET_MID_ONLY(256, 4)
-  CET_MID_ONLY(512, 1) CET_MID_ONLY(512, 2) CET_MID_ONLY(512, 3)
-#undef CET_MID_ONLY
+#undef CET_MID_S
   return CET_ERR_UNSUPPORTED;
 }
 // a == nullptr: prepare
@@ -1799,13 +1800,13 @@ static int mid_dispatch(const RnnModel* m, const RArgs* a, int S, hipStream_t s)
 }
 
 static int rnn_prepare(const RnnModel* m) {
-  if (!m->core) return mid_dispatch(m, nullptr, 1, nullptr);
+  for (int S = 1; S <= 8; S *= 2)
+    if (mid_share_ok(m->H, S))
+      if (const int rc = mid_dispatch(m, nullptr, S, nullptr)) return rc;
+  if (!m->core) return CET_OK;
   PrepareFn pf;
   LaunchFn lf;
   if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
-  for (int S = 1; S <= 4; S *= 2)
-    if (S == 1 || m->H / S >= 64)
-      if (const int rc = mid_dispatch(m, nullptr, S, nullptr)) return rc;
   return pf();
 }
 
@@ -1915,7 +1916,7 @@ static SplitPlan split_plan(const RnnModel* m, int tiles) {
 //   + 0.6 (1.0) us per step.
 static void rnn_split_limits(RnnModel* m) {
   int tiles = 0;
-  while (tiles < 4096 && split_plan(m, tiles + 1).uw) ++tiles;
+  while (m->core && tiles < 4096 && split_plan(m, tiles + 1).uw) ++tiles;
   m->split_chunk = tiles * ST;
   const int G = gates_of(m->kind), H = m->H;
   double tiled = 0.0;
@@ -1940,22 +1941,24 @@ static double split_step_estimate(const RnnModel* m, int tiles) {
 }
 
 // The kernel for a batch under the automatic choice: 1 batch-tiled, 2 hidden-split (in chunks), 4 / 5
-// / 6 half-tile with 1 / 2 / 4 workgroups per tile; the least estimated time. pooled: kernels that
+// / 6 / 8 half-tile with 1 / 2 / 4 / 8 workgroups per tile; the least estimated time. pooled: kernels that
 // exchange through a buffer of the pool are allowed (not under stream capture).
 static int rnn_choose(const RnnModel* m, int B, bool pooled) {
   const long tiles = (B + MT - 1) / MT;
-  int best = 1;
-  double t_best = m->est_tiled_step * ((B + 32L * m->cus - 1) / (32L * m->cus));
-  for (int S = 1; S <= 4; S *= 2) {
-    if (tiles * S > m->cus || (S > 1 && (!pooled || !m->wstream_shared[S == 2 ? 1 : 2]))) continue;
+  // the batch-tiled kernel, or for the shapes it does not serve the half-tile kernel in rounds
+  int best = m->core ? 1 : 4;
+  double t_best = m->core ? m->est_tiled_step * ((B + 32L * m->cus - 1) / (32L * m->cus))
+                          : 0.56 * m->est_tiled_step * ((tiles + m->cus - 1) / m->cus);
+  for (int S = 1, si = 0; S <= 8; S *= 2, ++si) {
+    if (tiles * S > m->cus || (S > 1 && (!pooled || !m->wstream_shared[si]))) continue;
     if (S > 1 && (size_t)tiles * m->layers > SPLIT_CNT_SLOTS) continue;
     const double t = 0.56 * m->est_tiled_step / S + (S > 1 ? 0.6 + 1.95 * m->layers : 0.0);
     if (t < t_best) {
       t_best = t;
-      best = S == 1 ? 4 : (S == 2 ? 5 : 6);
+      best = S == 1 ? 4 : (S == 2 ? 5 : (S == 4 ? 6 : 8));
     }
   }
-  if (pooled && m->split_chunk > 0) {
+  if (pooled && m->core && m->split_chunk > 0) {
     const int full = B / m->split_chunk, rest = B % m->split_chunk;
     double t = full ? full * split_step_estimate(m, m->split_chunk / ST) : 0.0;
     if (rest) t += split_step_estimate(m, (rest + ST - 1) / ST);
@@ -2041,10 +2044,10 @@ static int rollout_split(const RnnModel* m, const float* x, float* out, int B, i
 }
 
 // The shared half-tile rollout (S workgroups per 16-sequence tile) on `scratch`: zeroes the counters,
-// launches, and launches the batch-tiled kernel behind it on condition of the failure flag.
+// launches, and launches the unshared half-tile kernel behind it on condition of the failure flag.
 static int rollout_shared(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                           int S, float* scratch, hipStream_t stream) {
-  const int si = S == 2 ? 1 : 2;
+  const int si = S == 2 ? 1 : (S == 4 ? 2 : 3);
   const long tiles = (B + MT - 1) / MT;
   if (!m->wstream_shared[si] || tiles * S > m->cus || (size_t)tiles * m->layers > SPLIT_CNT_SLOTS)
     return CET_ERR_TOO_LARGE;
@@ -2055,12 +2058,11 @@ static int rollout_shared(const RnnModel* m, const float* x, float* out, int B, 
   a.spin_limit = m->variant == 7 ? 0 : SPIN_LIMIT;  // 7: the exchange gives up at its first unanswered poll (tests)
   CET_HIP(hipMemsetAsync(scratch, 0, SPLIT_CNT_FLOATS * sizeof(float), stream));
   if (const int rc = mid_dispatch(m, &a, S, stream)) return rc;
+  // on stand-by: the half-tile kernel with a tile per workgroup (every shape has it)
   RArgs t = tiled_args(m, x, out, B, seq_len, pred_len);
+  t.wstream = m->wstream_mid;
   t.only_if = a.cnt + (SPLIT_CNT_FLOATS - 1);
-  PrepareFn pf;
-  LaunchFn lf;
-  if (!variant(m->kind, m->H / 128, m->layers, &pf, &lf)) return CET_ERR_UNSUPPORTED;
-  return lf(t, stream);
+  return mid_dispatch(m, &t, 1, stream);
 }
 
 // Claims an exchange buffer of this device's pool for launches on `stream` (see SplitPool). The
@@ -2068,9 +2070,9 @@ static int rollout_shared(const RnnModel* m, const float* x, float* out, int B, 
 static int split_claim(const RnnModel* m, SplitPool& pool, hipStream_t stream, int* slot_out) {
   // hidden-split launches: up to SPLIT_MAX_OCC * CUs workgroup-slices of 256 floats per layer and parity;
   // shared half-tile launches: up to CUs / 2 tiles of 16 x 256 floats
-  const size_t per_lp = (size_t)SPLIT_MAX_OCC * m->cus * 256 > (size_t)(m->cus / 2) * MT * 256
-                            ? (size_t)SPLIT_MAX_OCC * m->cus * 256 : (size_t)(m->cus / 2) * MT * 256;
-  const size_t need = (SPLIT_CNT_FLOATS + per_lp * SPLIT_MAX_LAYERS * 2) * sizeof(float);
+  // (up to 512 hidden units and 4 layers: sized for the largest shape, so that a slot never grows)
+  const size_t per_lp = (size_t)(m->cus / 2) * MT * 512;
+  const size_t need = (SPLIT_CNT_FLOATS + per_lp * 4 * 2) * sizeof(float);
   if (pool.slot_bytes < need) {  // first use on this device (the CU count of a device is fixed)
     for (int i = 0; i < SPLIT_SLOTS; ++i) {
       SplitSlot& sl = pool.slot[i];
@@ -2128,10 +2130,8 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   const int chunk = split_chunk(m);
   if (B <= 0) return CET_OK;
   int kernel = m->variant;  // 1 batch-tiled, 2 / 3 hidden-split, 4 / 5 / 6 half-tile on 1 / 2 / 4 workgroups
-  if (!m->core) {  // hidden 64 / 512 or 4 layers: the half-tile kernel, in as many rounds of workgroups as it takes
-    if (kernel != 0 && kernel != 4) return CET_ERR_UNSUPPORTED;
-    kernel = 4;
-  }
+  // hidden 64 / 512 or 4 layers: the half-tile kernels only
+  if (!m->core && (kernel == 1 || kernel == 2 || kernel == 3)) return CET_ERR_UNSUPPORTED;
   if (kernel == 0) kernel = rnn_choose(m, B, true);
   if (kernel == 2 || kernel == 3 || kernel >= 5) {
     // These exchange through a buffer of the pool. Under stream capture the launches would be
@@ -2145,7 +2145,7 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
     }
   }
   const bool split = (kernel == 2 || kernel == 3) && chunk > 0;
-  const int shared = kernel == 5 || kernel == 7 ? 2 : (kernel == 6 ? 4 : 0);  // workgroups per half tile
+  const int shared = kernel == 5 || kernel == 7 ? 2 : (kernel == 6 ? 4 : (kernel == 8 ? 8 : 0));  // workgroups per half tile
   if ((kernel == 2 || kernel == 3) && !split) return CET_ERR_TOO_LARGE;
   if (split || shared) {
     if (m->device < 0 || m->device >= SPLIT_MAX_DEVICES) return CET_ERR_UNSUPPORTED;

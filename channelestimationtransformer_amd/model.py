@@ -324,7 +324,7 @@ class _RecurrentBase(_DeviceWeights):
         return h, None
 
     _KERNELS = {"auto": 0, "tiled": 1, "split": 2, "split_giveup": 3, "half_tile": 4, "half_tile_2": 5, "half_tile_4": 6,
-                "half_tile_2_giveup": 7}
+                "half_tile_2_giveup": 7, "half_tile_8": 8}
 
     def select_kernel(self, kernel):
         """Pins the rollout kernel (tests, timing): "tiled" (a workgroup takes 32 sequences and all

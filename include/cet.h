@@ -142,8 +142,8 @@ size_t cet_rnn_blob_size(int kind, int features, int input_size, int hidden_size
  * 4 up to 32, hidden_size 64, 128, 256 or 512, 1 to 4 layers (3 at 512), input_size 1 to 4096
  * (the encoder Linear is folded into the first layer's input weights at create time, in double
  * precision). Hidden 128 / 256 with up to 3 layers are served by every kernel of cet_rnn_select;
- * the other shapes by the half-tile kernel alone, at every batch size (choices 0 and 4; the
- * others and cet_rnn_rollout_static return CET_ERR_UNSUPPORTED). */
+ * the other shapes by the half-tile kernels alone (choices 0 and 4 .. 8; 1 .. 3 and
+ * cet_rnn_rollout_static return CET_ERR_UNSUPPORTED). */
 int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int num_layers,
                    const float* weights, size_t n_weights, cet_handle* out);
 
@@ -154,7 +154,7 @@ int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int 
 int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len,
                     int pred_len, void* stream);
 
-/* Pins the kernel of later rollouts of this handle (tests and timing; 0..7): 0 by batch size, 1 the
+/* Pins the kernel of later rollouts of this handle (tests and timing; 0..8): 0 by batch size, 1 the
  * batch-tiled kernel (a workgroup takes 32 sequences and all hidden units), 2 the hidden-split
  * kernel for small batches (16 sequences and 4, 8 or 16 hidden units per workgroup - as few as
  * keeps the launch's workgroups resident at once, so that a small batch spreads over the whole
@@ -167,8 +167,9 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * the half-tile kernel (the batch-tiled design with 16 sequences per workgroup: 0.55 of its time
  * up to 16 sequences per CU), 5 / 6 the same with a tile's hidden units shared by 2 / 4 workgroups
  * that exchange their states like the hidden-split kernel's (up to 8 / 4 sequences per CU; 6 needs
- * 256 hidden units; CET_ERR_TOO_LARGE beyond), 7 as 5 with an exchange that gives up like 3. Choice
- * 0 takes the kernel with the least estimated time for the batch.
+ * 256 hidden units; CET_ERR_TOO_LARGE beyond), 7 as 5 with an exchange that gives up like 3, 8 as 5
+ * on 8 workgroups (512 hidden units; up to 2 sequences per CU). Choice 0 takes the kernel with the
+ * least estimated time for the batch. Behind a launch of 5 .. 8 the stand-by launch is choice 4's.
  * Rollouts on the kernels that exchange (2, 3, 5, 6, 7) may overlap freely, on any streams and handles and from any
  * host threads: each call claims one of four exchange buffers per GPU (a call that finds all four in flight on other
  * streams queues its stream behind one of them), and behind every hidden-split launch the
@@ -182,7 +183,7 @@ int cet_rnn_select(cet_handle h, int kernel);
 
 /* cet_rnn_rollout for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc): always the hidden-split kernel, with its
- * exchange buffer in a static device array of the library (1.5 MiB per GPU) instead of the buffer
+ * exchange buffer in a static device array of the library (1.6 MiB per GPU) instead of the buffer
  * cet_rnn_rollout allocates on its first small batch. Calls hipMalloc / hipFree on no path.
  * Limit: ceil(B / 16) * hidden / 16 <= 256 (B <= 256 at hidden 256, B <= 512 at hidden 128) and
  * the launch's workgroups resident at once (CU count, twice that where two fit a CU), else
