@@ -763,6 +763,20 @@ def secondary_lines(ctx, args, model, ck, x, xd, want_maps, dev_s):
             mid[f"{kind}_pred5_ms"] = dm * 1e3
             mid[f"{kind}_predictions_per_s"] = nb / dm
         extra[f"batch_{nb}_rollout"] = mid
+    # shapes beyond the shipped checkpoints' (hidden 512; random weights): the half-tile kernels alone,
+    # a tile's hidden units on 8 workgroups at 512 sequences, one workgroup per tile at 4096
+    wide = {}
+    for cls, G, H, NL in (("GRU", 3, 512, 2), ("LSTM", 4, 512, 3)):
+        torch.manual_seed(0)
+        wm = getattr(cet, cls)(16, 16, H, NL).eval()
+        for nb in (512, 4096):
+            xm = x[:nb].contiguous()
+            dm = timed_steady(lambda: wm.test_data(xm, 5, dev), dev)
+            fl = 29 * 2 * G * (H * (16 + H) + (NL - 1) * 2 * H * H) * nb
+            wide[f"{cls.lower()}_{H}x{NL}_B{nb}_pred5"] = {
+                "ms": dm * 1e3, "predictions_per_s": nb / dm, "mfma_frac": fl / dm / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        del wm
+    extra["recurrent_hidden_512"] = wide
 
     # ---- recurrent rollouts, 8192 sequences, pred_len 5 / 25 / 100 ------------------------------
     for kind in ("lstm", "gru", "rnn"):
