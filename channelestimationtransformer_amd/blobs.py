@@ -134,28 +134,58 @@ def informer_blob_len(cfg):
     return n
 
 
-def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers):
+RNN_HIDDEN_SIZES = (64, 128, 256, 512)  # hidden sizes the kernels are instantiated for
+
+
+def padded_hidden(hidden_size):
+    """The kernels' hidden size that serves `hidden_size`: the next of 64 / 128 / 256 / 512. The
+    units in between are padding (see pack_rnn)."""
+    for h in RNN_HIDDEN_SIZES:
+        if hidden_size <= h:
+            return h
+    raise ValueError(f"hidden_size {hidden_size}: the recurrent kernels take up to {RNN_HIDDEN_SIZES[-1]} hidden units")
+
+
+def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers, pad_to=None):
     """state_dict of RNN/GRU/LSTM (keys `model.encoder.0.*`, `model.<cell>.weight_ih_l0` ...)
-    -> 1-D float32 array in the C ABI's order."""
+    -> 1-D float32 array in the C ABI's order.
+
+    pad_to: lay the parameters out for `pad_to` >= hidden_size hidden units. The added units have
+    zero weights and biases on every side: their gates are sigma(0) / tanh(0), so starting from the
+    zero state they stay at exactly zero (tanh cell: tanh(0); GRU: 0.5 * 0 + 0.5 * h; LSTM: c = 0.5
+    c + 0.5 * 0, h = 0.5 tanh(c)), and nothing reads them through the zero columns. The real units'
+    sums gain terms of exactly zero: same results as the unpadded model."""
     sd = normalize_state_dict(sd)
     cell = {0: "rnn", 1: "gru", 2: "lstm"}[kind]
     G = RNN_GATES[kind]
+    H, Hp = hidden_size, pad_to or hidden_size
+    if Hp < H:
+        raise ValueError(f"pad_to {Hp} < hidden_size {H}")
     parts = []
 
-    def put(key, shape):
+    def get(key, shape):
         a = _np(sd[key])
         if tuple(a.shape) != tuple(shape):
             raise ValueError(f"{key}: shape {tuple(a.shape)} != expected {tuple(shape)}")
-        parts.append(a.reshape(-1))
+        return a
 
-    put("model.encoder.0.weight", (input_size, features))
-    put("model.encoder.0.bias", (input_size,))
+    def gates(a, cols):
+        """[G*H, ...] -> [G*Hp, cols]: every gate's rows at g * Hp, zero rows and columns behind."""
+        a = a.reshape(G, H, -1)
+        out = np.zeros((G, Hp, cols), np.float32)
+        out[:, :H, :a.shape[2]] = a
+        return out.reshape(-1)
+
+    parts.append(get("model.encoder.0.weight", (input_size, features)).reshape(-1))
+    parts.append(get("model.encoder.0.bias", (input_size,)).reshape(-1))
     for l in range(num_layers):
-        inp = input_size if l == 0 else hidden_size
-        put(f"model.{cell}.weight_ih_l{l}", (G * hidden_size, inp))
-        put(f"model.{cell}.weight_hh_l{l}", (G * hidden_size, hidden_size))
-        put(f"model.{cell}.bias_ih_l{l}", (G * hidden_size,))
-        put(f"model.{cell}.bias_hh_l{l}", (G * hidden_size,))
-    put("model.decoder.0.weight", (features, hidden_size))
-    put("model.decoder.0.bias", (features,))
+        inp = input_size if l == 0 else H
+        parts.append(gates(get(f"model.{cell}.weight_ih_l{l}", (G * H, inp)), input_size if l == 0 else Hp))
+        parts.append(gates(get(f"model.{cell}.weight_hh_l{l}", (G * H, H)), Hp))
+        parts.append(gates(get(f"model.{cell}.bias_ih_l{l}", (G * H,)), 1))
+        parts.append(gates(get(f"model.{cell}.bias_hh_l{l}", (G * H,)), 1))
+    dec = np.zeros((features, Hp), np.float32)
+    dec[:, :H] = get("model.decoder.0.weight", (features, H))
+    parts.append(dec.reshape(-1))
+    parts.append(get("model.decoder.0.bias", (features,)).reshape(-1))
     return np.concatenate(parts)

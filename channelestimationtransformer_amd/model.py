@@ -310,11 +310,13 @@ class _RecurrentBase(_DeviceWeights):
 
     def _create(self, device_index):
         kind = blobs.RNN_KINDS[self._cell]
+        # hidden sizes between the kernels' (64 / 128 / 256 / 512) run with zero units added
+        hp = blobs.padded_hidden(self.hidden_size)
         blob = np.ascontiguousarray(blobs.pack_rnn(self.state_dict(), kind, self.features,
                                                    self.input_size, self.hidden_size,
-                                                   self.num_layers))
+                                                   self.num_layers, pad_to=hp))
         h = ctypes.c_void_p()
-        rc = _cabi.lib().cet_rnn_create(kind, self.features, self.input_size, self.hidden_size,
+        rc = _cabi.lib().cet_rnn_create(kind, self.features, self.input_size, hp,
                                         self.num_layers, blob.ctypes.data_as(ctypes.c_void_p),
                                         blob.size, ctypes.byref(h))
         _cabi.check(rc, "cet_rnn_create")

@@ -143,7 +143,9 @@ size_t cet_rnn_blob_size(int kind, int features, int input_size, int hidden_size
  * (the encoder Linear is folded into the first layer's input weights at create time, in double
  * precision). Hidden 128 / 256 with up to 3 layers are served by every kernel of cet_rnn_select;
  * the other shapes by the half-tile kernels alone (choices 0 and 4 .. 8; 1 .. 3 and
- * cet_rnn_rollout_static return CET_ERR_UNSUPPORTED). */
+ * cet_rnn_rollout_static return CET_ERR_UNSUPPORTED). A model with another hidden size runs as the
+ * next of these sizes with zero units added (zero weights and biases on every side: the added
+ * units stay at zero and no result changes); the Python classes lay the blob out that way. */
 int cet_rnn_create(int kind, int features, int input_size, int hidden_size, int num_layers,
                    const float* weights, size_t n_weights, cet_handle* out);
 

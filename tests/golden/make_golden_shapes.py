@@ -1,5 +1,6 @@
 """Golden vectors for recurrent shapes beyond hidden 128 / 256 and three layers: GRU(16, 32, 512, 1),
-LSTM(16, 16, 64, 4), RNN(16, 32, 256, 4), 48 sequences of 25 slots, pred_len 5.
+LSTM(16, 16, 64, 4), RNN(16, 32, 256, 4), and for hidden sizes between the kernels' (100, 200, 300,
+40), 48 sequences of 25 slots, pred_len 5.
 
 Runs ONLY in the build container: imports the reference's model classes from /root/reference on
 the CPU (LocalSimulations/models/model.py:276, 350, 426 and their test_data methods :298-312,
@@ -26,7 +27,10 @@ from channelestimationtransformer_amd import synth  # noqa: E402
 from channelestimationtransformer_amd.utils import LoadBatch  # noqa: E402
 
 torch.set_num_threads(4)
-CASES = (("GRU", GRU, (16, 32, 512, 1)), ("LSTM", LSTM, (16, 16, 64, 4)), ("RNN", RNN, (16, 32, 256, 4)))
+CASES = (("GRU", GRU, (16, 32, 512, 1)), ("LSTM", LSTM, (16, 16, 64, 4)), ("RNN", RNN, (16, 32, 256, 4)),
+         # hidden sizes between the kernels' (the host side adds zero units up to 128 / 256 / 512 / 64)
+         ("GRU100", GRU, (16, 16, 100, 2)), ("LSTM200", LSTM, (16, 32, 200, 3)), ("RNN300", RNN, (16, 16, 300, 1)),
+         ("GRU40", GRU, (16, 16, 40, 1)))
 
 
 def main():

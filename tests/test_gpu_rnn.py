@@ -326,3 +326,33 @@ def test_other_shapes_against_the_imported_reference(cell):
     out = m.test_data(x, 5, "cuda").cpu().numpy()
     assert out.shape == want.shape == (48, 5, 16)
     assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("case", ["GRU100", "LSTM200", "RNN300", "GRU40"])
+def test_hidden_sizes_between_the_kernels_against_the_imported_reference(case):
+    """Hidden sizes the kernels are not instantiated for (the reference's classes take any,
+    LocalSimulations/models/model.py:276, 350, 426) run with zero units added up to the next of
+    64 / 128 / 256 / 512 (blobs.pack_rnn): GRU(16,16,100,2), LSTM(16,32,200,3), RNN(16,16,300,1),
+    GRU(16,16,40,1) against the imported reference (tests/golden/make_golden_shapes.py), on the
+    automatic choice and on every kernel that takes the padded shape."""
+    v = load_npz("rnn_shapes.npz")
+    shape = tuple(int(n) for n in v[f"{case}/shape"])
+    cell = case.rstrip("0123456789")
+    m = getattr(cet, cell)(*shape)
+    m.load_state_dict({k: torch.from_numpy(np.array(a)) for k, a in sub_dict(v, f"{case}/sd").items()})
+    m.eval()
+    x = torch.from_numpy(v["x"]).cuda()
+    want = v[f"{case}/pred5"]
+    tol = 5e-5 * max(1.0, float(np.abs(want).max()))
+    ran = 0
+    for variant in ("auto", "tiled", "split", "half_tile", "half_tile_2", "half_tile_4"):
+        try:
+            out = m.select_kernel(variant).test_data(x, 5, "cuda").cpu().numpy()
+        except RuntimeError:
+            assert variant != "auto" and variant != "half_tile"  # every shape has these
+            continue
+        ran += 1
+        assert out.shape == want.shape == (48, 5, 16)
+        assert np.abs(out - want).max() < tol, variant
+    assert ran >= 2
+

@@ -230,3 +230,29 @@ def test_checker_on_the_12_head_35_slot_checkpoint(oracle):
     for i, a in enumerate(attn):
         assert a.shape == v[f"h12/attn_{i}"].shape
         assert np.abs(a - v[f"h12/attn_{i}"]).max() < TOL, f"attention map {i}"
+
+
+@pytest.mark.parametrize("cell,kind", [("RNN", 0), ("GRU", 1), ("LSTM", 2)])
+def test_zero_units_added_to_the_hidden_state_change_nothing(cell, kind, oracle):
+    """blobs.pack_rnn(pad_to=...) lays a model of 100 hidden units out for 128 with zero weights and
+    biases for the added units: the checker's rollout on the padded parameters equals the one on
+    the original ones bit for bit (the added products are exact zeros), and on the imported
+    reference's GRU(16,16,100,2) it matches the stored outputs."""
+    import torch
+    import channelestimationtransformer_amd as cet
+    torch.manual_seed(5)
+    m = getattr(cet, cell)(16, 32, 100, 3)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    x = np.random.default_rng(3).standard_normal((9, 12, 16)).astype(np.float32)
+    plain = oracle.rnn_rollout(kind, 16, 32, 100, 3, blobs.pack_rnn(sd, kind, 16, 32, 100, 3), x, 4)
+    padded = oracle.rnn_rollout(kind, 16, 32, 128, 3, blobs.pack_rnn(sd, kind, 16, 32, 100, 3, pad_to=128), x, 4)
+    assert np.array_equal(plain, padded)
+    assert blobs.padded_hidden(100) == 128 and blobs.padded_hidden(64) == 64 and blobs.padded_hidden(300) == 512
+    with pytest.raises(ValueError):
+        blobs.padded_hidden(513)
+    if cell == "GRU":
+        v = load_npz("rnn_shapes.npz")
+        sd = sub_dict(v, "GRU100/sd")
+        out = oracle.rnn_rollout(1, 16, 16, 128, 2, blobs.pack_rnn(sd, 1, 16, 16, 100, 2, pad_to=128), v["x"], 5)
+        assert np.abs(out - v["GRU100/pred5"]).max() < 2e-5
+
