@@ -1943,7 +1943,7 @@ static double split_step_estimate(const RnnModel* m, int tiles) {
 // The kernel for a batch under the automatic choice: 1 batch-tiled, 2 hidden-split (in chunks), 4 / 5
 // / 6 / 8 half-tile with 1 / 2 / 4 / 8 workgroups per tile; the least estimated time. pooled: kernels that
 // exchange through a buffer of the pool are allowed (not under stream capture).
-static int rnn_choose(const RnnModel* m, int B, bool pooled) {
+static int rnn_choose(const RnnModel* m, int B, bool pooled, double* t_out = nullptr) {
   const long tiles = (B + MT - 1) / MT;
   // the batch-tiled kernel, or for the shapes it does not serve the half-tile kernel in rounds
   int best = m->core ? 1 : 4;
@@ -1962,8 +1962,12 @@ static int rnn_choose(const RnnModel* m, int B, bool pooled) {
     const int full = B / m->split_chunk, rest = B % m->split_chunk;
     double t = full ? full * split_step_estimate(m, m->split_chunk / ST) : 0.0;
     if (rest) t += split_step_estimate(m, (rest + ST - 1) / ST);
-    if (t < t_best) best = 2;
+    if (t < t_best) {
+      t_best = t;
+      best = 2;
+    }
   }
+  if (t_out) *t_out = t_best;
   return best;
 }
 
@@ -2117,8 +2121,57 @@ int rnn_rollout_static(const RnnModel* m, const float* x, float* out, int B, int
 // Sequences one launch of the hidden-split kernel takes on this handle's device (whole tiles).
 static int split_chunk(const RnnModel* m) { return m->split_chunk; }
 
+static int rollout_with(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                        int kernel, hipStream_t stream);
+
 int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
                 hipStream_t stream) {
+  if (B <= 0) return CET_OK;
+  if (m->variant != 0) return rollout_with(m, x, out, B, seq_len, pred_len, m->variant, stream);
+  // The automatic choice, part by part. Whole rounds of the batch-tiled kernel (32 sequences per CU)
+  // go in one launch; what is left goes to the kernel with the least estimated time, or, between
+  // 16 and 32 sequences per CU, to one round of half tiles followed by a rollout of the rest when
+  // the two together beat a round of full tiles (5,000 sequences, GRU: 1.10 + 0.37 ms instead of
+  // 2.0). Shapes without the batch-tiled kernel: whole rounds of half tiles, then the rest.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  CET_HIP(hipStreamIsCapturing(stream, &cap));
+  const bool pooled = cap == hipStreamCaptureStatusNone;  // see rollout_with()
+  const long round_full = 32L * m->cus, round_half = (long)MT * m->cus;
+  const size_t xs = (size_t)seq_len * m->F, os = (size_t)pred_len * m->F;
+  long done = 0;
+  while (done < B) {
+    const long rem = B - done;
+    long nb = rem;
+    int kernel;
+    if (m->core && rem >= round_full) {
+      nb = rem / round_full * round_full;
+      kernel = 1;
+    } else if (!m->core && rem > round_half) {
+      nb = rem / round_half * round_half;
+      kernel = 4;
+    } else {
+      double t_one = 0.0, t_rest = 0.0;
+      kernel = rnn_choose(m, (int)rem, pooled, &t_one);
+      if (rem > round_half) {
+        rnn_choose(m, (int)(rem - round_half), pooled, &t_rest);
+        if (0.56 * m->est_tiled_step + t_rest + 0.35 < t_one) {  // 0.35 us per step: a second launch (10 us per rollout of 29)
+          nb = round_half;
+          kernel = 4;
+        }
+      }
+    }
+    if (const int rc = rollout_with(m, x + (size_t)done * xs, out + (size_t)done * os, (int)nb, seq_len, pred_len,
+                                    kernel, stream))
+      return rc;
+    done += nb;
+  }
+  return CET_OK;
+}
+
+// One rollout on one kernel (1 batch-tiled, 2 / 3 hidden-split, 4 / 5 / 6 / 8 half-tile on 1 / 2 / 4 / 8
+// workgroups per tile, 7 as 5 with an exchange that gives up).
+static int rollout_with(const RnnModel* m, const float* x, float* out, int B, int seq_len, int pred_len,
+                        int kernel, hipStream_t stream) {
   // Small and medium batches: hidden units split over workgroups (a batch-tiled rollout of 64
   // sequences keeps 2 of the CUs busy for as long as one of 8192 keeps all of them busy). One
   // launch takes as many sequences as its workgroups are resident at once, each with one or two
@@ -2129,10 +2182,8 @@ int rnn_rollout(const RnnModel* m, const float* x, float* out, int B, int seq_le
   // 0.70 ms).
   const int chunk = split_chunk(m);
   if (B <= 0) return CET_OK;
-  int kernel = m->variant;  // 1 batch-tiled, 2 / 3 hidden-split, 4 / 5 / 6 half-tile on 1 / 2 / 4 workgroups
   // hidden 64 / 512 or 4 layers: the half-tile kernels only
   if (!m->core && (kernel == 1 || kernel == 2 || kernel == 3)) return CET_ERR_UNSUPPORTED;
-  if (kernel == 0) kernel = rnn_choose(m, B, true);
   if (kernel == 2 || kernel == 3 || kernel >= 5) {
     // These exchange through a buffer of the pool. Under stream capture the launches would be
     // replayed later, outside the pool's bookkeeping: the kernels that need no buffer serve then

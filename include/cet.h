@@ -171,7 +171,9 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * that exchange their states like the hidden-split kernel's (up to 8 / 4 sequences per CU; 6 needs
  * 256 hidden units; CET_ERR_TOO_LARGE beyond), 7 as 5 with an exchange that gives up like 3, 8 as 5
  * on 8 workgroups (512 hidden units; up to 2 sequences per CU). Choice 0 takes the kernel with the
- * least estimated time for the batch. Behind a launch of 5 .. 8 the stand-by launch is choice 4's.
+ * least estimated time for the batch, and a batch beyond 16 sequences per CU in parts (whole rounds
+ * of full or half tiles, then the rest: several launches on the stream, disjoint ranges of x and
+ * out). Behind a launch of 5 .. 8 the stand-by launch is choice 4's.
  * Rollouts on the kernels that exchange (2, 3, 5, 6, 7) may overlap freely, on any streams and handles and from any
  * host threads: each call claims one of four exchange buffers per GPU (a call that finds all four in flight on other
  * streams queues its stream behind one of them), and behind every hidden-split launch the
