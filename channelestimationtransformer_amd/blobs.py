@@ -48,9 +48,29 @@ def make_informer_cfg(enc_in, dec_in, c_out, seq_len, label_len, out_len, d_mode
                        activation=0 if activation == "relu" else 1)
 
 
-def pack_informer(sd, cfg):
-    """state_dict (reference key names) -> 1-D float32 array in the C ABI's order."""
+def padded_informer_cfg(cfg):
+    """The configuration the kernels run for `cfg`: enc_in / dec_in of 16 or 32 input features and a
+    c_out that is a multiple of 4 (the kernels' widths). The added input features have zero
+    token-convolution weights and the added outputs zero projection rows and biases
+    (pack_informer(sd, cfg, dev_cfg)); the model classes add zero columns to the inputs and drop
+    the added outputs. Equal to `cfg` for the widths the kernels take as they are."""
+    def width(n, what):
+        if n <= 16:
+            return 16
+        if n <= 32:
+            return 32
+        raise ValueError(f"{what} {n}: the Transformer kernel takes up to 32 input features")
+    d = InformerCfg.from_buffer_copy(cfg)
+    d.enc_in, d.dec_in = width(cfg.enc_in, "enc_in"), width(cfg.dec_in, "dec_in")
+    d.c_out = (cfg.c_out + 3) // 4 * 4
+    return d
+
+
+def pack_informer(sd, cfg, dev_cfg=None):
+    """state_dict (reference key names) -> 1-D float32 array in the C ABI's order; with `dev_cfg`
+    (padded_informer_cfg) laid out for its enc_in / dec_in / c_out, zeros for what is added."""
     sd = normalize_state_dict(sd)
+    dev_cfg = dev_cfg or cfg
     parts = []
 
     def put(key, shape=None):
@@ -63,7 +83,13 @@ def pack_informer(sd, cfg):
     HE = (D // cfg.n_heads) * cfg.n_heads  # d_keys * n_heads (attn.py:121-138)
     for emb, cin, L in (("enc_embedding", cfg.enc_in, cfg.seq_len),
                         ("dec_embedding", cfg.dec_in, cfg.label_len + cfg.pred_len)):
-        put(f"{emb}.value_embedding.tokenConv.weight", (D, cin, 3))
+        w = _np(sd[f"{emb}.value_embedding.tokenConv.weight"])
+        if tuple(w.shape) != (D, cin, 3):
+            raise ValueError(f"{emb}.value_embedding.tokenConv.weight: shape {tuple(w.shape)} != expected {(D, cin, 3)}")
+        cpad = dev_cfg.enc_in if emb == "enc_embedding" else dev_cfg.dec_in
+        wp = np.zeros((D, cpad, 3), np.float32)
+        wp[:, :cin] = w
+        parts.append(wp.reshape(-1))
         put(f"{emb}.value_embedding.tokenConv.bias", (D,))
         pe = _np(sd[f"{emb}.position_embedding.pe"])
         parts.append(np.ascontiguousarray(pe.reshape(-1, D)[:L]).reshape(-1))
@@ -111,8 +137,12 @@ def pack_informer(sd, cfg):
             put(f"{p}.{n}.bias", (D,))
     put("decoder.norm.weight", (D,))
     put("decoder.norm.bias", (D,))
-    put("projection.weight", (cfg.c_out, D))
-    put("projection.bias", (cfg.c_out,))
+    pw, pb = _np(sd["projection.weight"]), _np(sd["projection.bias"])
+    if tuple(pw.shape) != (cfg.c_out, D) or tuple(pb.shape) != (cfg.c_out,):
+        raise ValueError(f"projection: shapes {tuple(pw.shape)}, {tuple(pb.shape)} != expected {(cfg.c_out, D)}, {(cfg.c_out,)}")
+    pwp, pbp = np.zeros((dev_cfg.c_out, D), np.float32), np.zeros((dev_cfg.c_out,), np.float32)
+    pwp[:cfg.c_out], pbp[:cfg.c_out] = pw, pb
+    parts += [pwp.reshape(-1), pbp]
     return np.concatenate(parts)
 
 
@@ -146,7 +176,15 @@ def padded_hidden(hidden_size):
     raise ValueError(f"hidden_size {hidden_size}: the recurrent kernels take up to {RNN_HIDDEN_SIZES[-1]} hidden units")
 
 
-def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers, pad_to=None):
+def padded_features(features):
+    """The recurrent kernels read rows of a multiple of 4 features, up to 32."""
+    fp = (features + 3) // 4 * 4
+    if fp > 32:
+        raise ValueError(f"features {features}: the recurrent kernels take up to 32 features")
+    return fp
+
+
+def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers, pad_to=None, pad_features=None):
     """state_dict of RNN/GRU/LSTM (keys `model.encoder.0.*`, `model.<cell>.weight_ih_l0` ...)
     -> 1-D float32 array in the C ABI's order.
 
@@ -154,7 +192,9 @@ def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers, pad_to=Non
     zero weights and biases on every side: their gates are sigma(0) / tanh(0), so starting from the
     zero state they stay at exactly zero (tanh cell: tanh(0); GRU: 0.5 * 0 + 0.5 * h; LSTM: c = 0.5
     c + 0.5 * 0, h = 0.5 tanh(c)), and nothing reads them through the zero columns. The real units'
-    sums gain terms of exactly zero: same results as the unpadded model."""
+    sums gain terms of exactly zero: same results as the unpadded model.
+    pad_features: lay the encoder and decoder Linear out for `pad_features` >= features (zero encoder
+    columns, zero decoder rows and biases): the added outputs are exactly zero and feed zeros back."""
     sd = normalize_state_dict(sd)
     cell = {0: "rnn", 1: "gru", 2: "lstm"}[kind]
     G = RNN_GATES[kind]
@@ -176,7 +216,12 @@ def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers, pad_to=Non
         out[:, :H, :a.shape[2]] = a
         return out.reshape(-1)
 
-    parts.append(get("model.encoder.0.weight", (input_size, features)).reshape(-1))
+    Fp = pad_features or features
+    if Fp < features:
+        raise ValueError(f"pad_features {Fp} < features {features}")
+    enc = np.zeros((input_size, Fp), np.float32)
+    enc[:, :features] = get("model.encoder.0.weight", (input_size, features))
+    parts.append(enc.reshape(-1))
     parts.append(get("model.encoder.0.bias", (input_size,)).reshape(-1))
     for l in range(num_layers):
         inp = input_size if l == 0 else H
@@ -184,8 +229,8 @@ def pack_rnn(sd, kind, features, input_size, hidden_size, num_layers, pad_to=Non
         parts.append(gates(get(f"model.{cell}.weight_hh_l{l}", (G * H, H)), Hp))
         parts.append(gates(get(f"model.{cell}.bias_ih_l{l}", (G * H,)), 1))
         parts.append(gates(get(f"model.{cell}.bias_hh_l{l}", (G * H,)), 1))
-    dec = np.zeros((features, Hp), np.float32)
-    dec[:, :H] = get("model.decoder.0.weight", (features, H))
-    parts.append(dec.reshape(-1))
-    parts.append(get("model.decoder.0.bias", (features,)).reshape(-1))
+    dec, dec_b = np.zeros((Fp, Hp), np.float32), np.zeros((Fp,), np.float32)
+    dec[:features, :H] = get("model.decoder.0.weight", (features, H))
+    dec_b[:features] = get("model.decoder.0.bias", (features,))
+    parts += [dec.reshape(-1), dec_b]
     return np.concatenate(parts)

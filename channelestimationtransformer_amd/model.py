@@ -201,10 +201,12 @@ class _InformerBase(_DeviceWeights):
         self.projection = nn.Linear(d_model, c_out, bias=True)
 
     def _create(self, device_index):
-        blob = np.ascontiguousarray(blobs.pack_informer(self.state_dict(), self._cfg))
+        # feature counts other than the kernels' widths: zero channels added (blobs.padded_informer_cfg)
+        dev_cfg = blobs.padded_informer_cfg(self._cfg)
+        blob = np.ascontiguousarray(blobs.pack_informer(self.state_dict(), self._cfg, dev_cfg))
         L = _cabi.lib()
         h = ctypes.c_void_p()
-        rc = L.cet_informer_create(ctypes.byref(self._cfg), blob.ctypes.data_as(ctypes.c_void_p),
+        rc = L.cet_informer_create(ctypes.byref(dev_cfg), blob.ctypes.data_as(ctypes.c_void_p),
                                    blob.size, ctypes.byref(h))
         _cabi.check(rc, "cet_informer_create")
         choice = self._kernel_choice
@@ -246,8 +248,15 @@ class _InformerBase(_DeviceWeights):
             raise RuntimeError("x_enc is on the CPU: this implementation runs on ROCm GPUs only")
         handle, per_sample = self._handle_for(x_enc.device)
         want = per_sample if self.output_attention else 0
+        d = blobs.padded_informer_cfg(c)
+        if d.enc_in != c.enc_in:
+            x_enc = torch.nn.functional.pad(x_enc, (0, d.enc_in - c.enc_in))
+        if d.dec_in != c.dec_in:
+            x_dec = torch.nn.functional.pad(x_dec, (0, d.dec_in - c.dec_in))
         pred, attn = torch.ops.cet.informer_forward(x_enc, x_dec, handle, c.pred_len,
-                                                    c.c_out, want)
+                                                    d.c_out, want)
+        if d.c_out != c.c_out:
+            pred = pred[:, :, :c.c_out].contiguous()
         if not self.output_attention:
             return pred
         return pred, self._split_attention(attn, x_enc.shape[0])
@@ -311,12 +320,13 @@ class _RecurrentBase(_DeviceWeights):
     def _create(self, device_index):
         kind = blobs.RNN_KINDS[self._cell]
         # hidden sizes between the kernels' (64 / 128 / 256 / 512) run with zero units added
-        hp = blobs.padded_hidden(self.hidden_size)
+        # and feature counts that are no multiple of 4 with zero features added
+        hp, fp = blobs.padded_hidden(self.hidden_size), blobs.padded_features(self.features)
         blob = np.ascontiguousarray(blobs.pack_rnn(self.state_dict(), kind, self.features,
                                                    self.input_size, self.hidden_size,
-                                                   self.num_layers, pad_to=hp))
+                                                   self.num_layers, pad_to=hp, pad_features=fp))
         h = ctypes.c_void_p()
-        rc = _cabi.lib().cet_rnn_create(kind, self.features, self.input_size, hp,
+        rc = _cabi.lib().cet_rnn_create(kind, fp, self.input_size, hp,
                                         self.num_layers, blob.ctypes.data_as(ctypes.c_void_p),
                                         blob.size, ctypes.byref(h))
         _cabi.check(rc, "cet_rnn_create")
@@ -350,6 +360,10 @@ class _RecurrentBase(_DeviceWeights):
             raise RuntimeError(f"x must be [B, seq_len, {self.features}], got {tuple(x.shape)}")
         if not x.is_cuda:
             raise RuntimeError("x is on the CPU: this implementation runs on ROCm GPUs only")
+        fp = blobs.padded_features(self.features)
+        if fp != self.features:
+            x = torch.nn.functional.pad(x, (0, fp - self.features))
+            return torch.ops.cet.rnn_rollout(x, self._handle_for(x.device)[0], int(pred_len))[:, :, :self.features].contiguous()
         return torch.ops.cet.rnn_rollout(x, self._handle_for(x.device)[0], int(pred_len))
 
     def train_data(self, x, device=None):

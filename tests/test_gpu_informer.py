@@ -268,3 +268,29 @@ def test_default_kernel_choice_agrees(monkeypatch):
     small = m(x[-67:].contiguous(), xd[-67:].contiguous())  # one-wave kernel
     assert torch.isfinite(big).all()
     assert (big[-67:] - small).abs().max() < TOL_PRED
+
+
+@pytest.mark.parametrize("name,cls", [("stack8", "InformerStack"), ("informer24", "Informer")])
+def test_feature_counts_other_than_the_kernels_widths(name, cls):
+    """enc_in = dec_in = c_out = 8 (InformerStack) and enc_in = dec_in = 24, c_out = 22 (Informer)
+    against the imported reference (tests/golden/make_golden_widths.py;
+    LocalSimulations/models/model.py:67-81, 220-234): the classes add zero input channels and
+    output rows up to the kernels' widths (blobs.padded_informer_cfg) and drop them again."""
+    v = load_npz("widths.npz")
+    ei, di, co, sl, ll, pl, el, dl = (int(n) for n in v[f"{name}/args"])
+    m = getattr(cet, cls)(ei, di, co, sl, ll, pl, 5, 64, 8, el, dl, 64, 0.0, "full", "fixed", "gelu", True, True)
+    sd = m.state_dict()
+    for k, a in sub_dict(v, f"{name}/sd").items():
+        sd[k] = torch.from_numpy(np.array(a))
+    m.load_state_dict(sd)
+    m.eval()
+    x_enc, x_dec = torch.from_numpy(v[f"{name}/x_enc"]).cuda(), torch.from_numpy(v[f"{name}/x_dec"]).cuda()
+    for kernel in ("one_wave", "workgroup"):
+        pred, attns = m.select_kernel(kernel)(x_enc, x_dec)
+        assert tuple(pred.shape) == (6, pl, co)
+        assert np.abs(pred.cpu().numpy() - v[f"{name}/pred"]).max() < TOL_PRED, kernel
+        flat = []
+        for a in attns:
+            flat += list(a) if isinstance(a, (list, tuple)) else [a]
+        for i, a in enumerate(flat):
+            assert np.abs(a.cpu().numpy() - v[f"{name}/attn{i}"]).max() < TOL_ATTN, (kernel, i)

@@ -382,3 +382,22 @@ def test_batches_between_the_kernels_sizes_go_part_by_part(cell, H, layers, B, o
                               x[torch.from_numpy(idx).cuda()].cpu().numpy(), 6)
     assert np.abs(out[torch.from_numpy(idx).cuda()].cpu().numpy() - want).max() < 1e-4 * scale
 
+
+
+@pytest.mark.parametrize("name,cell", [("gru6", "GRU"), ("lstm10", "LSTM")])
+def test_feature_counts_that_are_no_multiple_of_4(name, cell):
+    """GRU with 6 features (a 3x1 channel) and LSTM with 10 against the imported reference
+    (tests/golden/make_golden_widths.py; LocalSimulations/models/model.py:373-388, 449-465): the
+    classes add zero features up to a multiple of 4 (blobs.pack_rnn(pad_features=...)) and drop
+    them from the output."""
+    v = load_npz("widths.npz")
+    shape = tuple(int(n) for n in v[f"{name}/shape"])
+    m = getattr(cet, cell)(*shape)
+    m.load_state_dict({k: torch.from_numpy(np.array(a)) for k, a in sub_dict(v, f"{name}/sd").items()})
+    m.eval()
+    x = torch.from_numpy(v[f"{name}/x"]).cuda()
+    want = v[f"{name}/pred5"]
+    for variant in ("auto", "tiled", "split", "half_tile"):
+        out = m.select_kernel(variant).test_data(x, 5, "cuda").cpu().numpy()
+        assert out.shape == want.shape == (20, 5, shape[0])
+        assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max())), variant

@@ -256,3 +256,32 @@ def test_zero_units_added_to_the_hidden_state_change_nothing(cell, kind, oracle)
         out = oracle.rnn_rollout(1, 16, 16, 128, 2, blobs.pack_rnn(sd, 1, 16, 16, 100, 2, pad_to=128), v["x"], 5)
         assert np.abs(out - v["GRU100/pred5"]).max() < 2e-5
 
+
+
+def test_checker_on_feature_counts_other_than_the_kernels_widths(oracle):
+    """InformerStack with 8 input / output features laid out for 16 (blobs.padded_informer_cfg,
+    pack_informer(sd, cfg, dev_cfg)): the checker on the padded parameters and zero-padded inputs
+    reproduces the imported reference's outputs and attention maps (tests/golden/make_golden_widths.py)."""
+    import torch
+    import channelestimationtransformer_amd as cet
+    v = load_npz("widths.npz")
+    ei, di, co, sl, ll, pl, el, dl = (int(n) for n in v["stack8/args"])
+    m = cet.InformerStack(ei, di, co, sl, ll, pl, 5, 64, 8, el, dl, 64, 0.0, "full", "fixed", "gelu", True, True)
+    sd = {k: t.numpy() for k, t in m.state_dict().items()}
+    sd.update(sub_dict(v, "stack8/sd"))
+    cfg = m._cfg
+    dev = blobs.padded_informer_cfg(cfg)
+    assert (dev.enc_in, dev.dec_in, dev.c_out) == (16, 16, 8)
+    blob = blobs.pack_informer(sd, cfg, dev)
+    assert blob.size == blobs.informer_blob_len(dev)
+    pad = lambda a, n: np.concatenate([a, np.zeros(a.shape[:2] + (n - a.shape[2],), np.float32)], 2)  # noqa: E731
+    pred, attn, _ = oracle.informer_forward(dev, blob, pad(v["stack8/x_enc"], 16), pad(v["stack8/x_dec"], 16),
+                                            want_attn=True, want_taps=True)
+    assert np.abs(pred[:, :, :co] - v["stack8/pred"]).max() < TOL * 4
+    for i, a in enumerate(attn):
+        assert np.abs(a - v[f"stack8/attn{i}"]).max() < TOL * 4, i
+    with pytest.raises(ValueError):
+        blobs.padded_informer_cfg(blobs.make_informer_cfg(40, 16, 16, 25, 10, 5, 64, 8, 4, 3, 64, True, True, "gelu"))
+    assert blobs.padded_features(6) == 8 and blobs.padded_features(16) == 16
+    with pytest.raises(ValueError):
+        blobs.padded_features(33)
