@@ -1895,7 +1895,16 @@ static long split_workgroups(const RnnModel* m, int tiles, SplitPlan pl) {
 static SplitPlan split_plan(const RnnModel* m, int tiles) {
   const bool tanh_cell = m->kind == CET_RNN_TANH;
   for (int uw = tanh_cell ? 16 : 4; uw <= 16; uw *= 2)
-    if (split_workgroups(m, tiles, {uw, 1}) <= split_capacity(m, {uw, 1}, false)) return {uw, 1};
+    if (split_workgroups(m, tiles, {uw, 1}) <= split_capacity(m, {uw, 1}, false)) {
+      // An instantiation the compiler had to spill for runs at about half its speed (LSTM, 3 layers
+      // of 256, 8 units: 0.43 ms for 96 sequences): rather the finer split with two workgroups per
+      // CU (0.33 ms), or the next coarser one.
+      if (uw == 8 && m->split_spill[1] > 256) {
+        if (split_workgroups(m, tiles, {4, 1}) <= split_capacity(m, {4, 1}, true)) return {4, 1};
+        continue;
+      }
+      return {uw, 1};
+    }
   if (tanh_cell && split_workgroups(m, tiles, {16, 1}) <= split_capacity(m, {16, 1}, true)) return {16, 1};
   // (not where two tiles' state costs the compiler registers it has to spill: LSTM, 3 layers of 256)
   if (m->split_spill[3] <= 256 && split_workgroups(m, tiles, {16, 2}) <= split_capacity(m, {16, 2}, false))
