@@ -462,7 +462,7 @@ constexpr int ST = 16;        // sequences per workgroup
 constexpr int CNT_STRIDE = 32;                 // words between counters
 constexpr size_t SPLIT_CNT_SLOTS = 767;        // counters the header has room for
 constexpr size_t SPLIT_CNT_FLOATS = (SPLIT_CNT_SLOTS + 1) * CNT_STRIDE;  // 96 KiB
-constexpr int SPIN_LIMIT = 1 << 20;  // polls of about a microsecond each: a second or two
+constexpr int SPIN_LIMIT = 1 << 17;  // polls of about a microsecond each: a tenth of a second or two, then the stand-by launch serves
 
 DEV f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -1478,6 +1478,7 @@ struct SplitSlot {
   hipEvent_t done = nullptr;
   hipStream_t last = nullptr;
   bool used = false;
+  int cus = 0;  // CUs the launches behind `done` need for all their workgroups to be resident at once
 };
 struct SplitPool {
   std::mutex mu;
@@ -2080,7 +2081,7 @@ static int rollout_shared(const RnnModel* m, const float* x, float* out, int B, 
 
 // Claims an exchange buffer of this device's pool for launches on `stream` (see SplitPool). The
 // caller holds pool.mu and keeps it until it has recorded the slot's event behind its launches.
-static int split_claim(const RnnModel* m, SplitPool& pool, hipStream_t stream, int* slot_out) {
+static int split_claim(const RnnModel* m, SplitPool& pool, hipStream_t stream, int need_cus, int* slot_out) {
   // hidden-split launches: up to SPLIT_MAX_OCC * CUs workgroup-slices of 256 floats per layer and parity;
   // shared half-tile launches: up to CUs / 2 tiles of 16 x 256 floats
   // (up to 512 hidden units and 4 layers: sized for the largest shape, so that a slot never grows)
@@ -2110,6 +2111,29 @@ static int split_claim(const RnnModel* m, SplitPool& pool, hipStream_t stream, i
   // finished, and it covers a new stream that was given the handle value of a destroyed one whose
   // work is still running.
   if (pool.slot[pick].used) CET_HIP(hipStreamWaitEvent(stream, pool.slot[pick].done, 0));
+  // Exchanging grids that are in flight together never ask for more CUs than the device has: a
+  // workgroup that waits for the others of its tile holds its CU, and with the XCDs placing their
+  // shares of a grid independently several grids could otherwise each hold part of the CUs the
+  // others' missing workgroups need (seen as rollouts that ended in the bounded wait and the
+  // stand-by launch when three streams launched 256-workgroup grids at once). Beyond that the
+  // stream waits, on the device, for earlier launches of other streams.
+  int busy = 0;
+  bool counts[SPLIT_SLOTS] = {};
+  for (int i = 0; i < SPLIT_SLOTS; ++i) {
+    const SplitSlot& sl = pool.slot[i];
+    if (i == pick || !sl.used || sl.last == stream) continue;  // the stream's own launches run before this one
+    const hipError_t q = hipEventQuery(sl.done);
+    if (q == hipSuccess) continue;
+    if (q != hipErrorNotReady) return hip_fail(q);
+    counts[i] = true;
+    busy += sl.cus;
+  }
+  for (int i = 0; i < SPLIT_SLOTS && busy + need_cus > m->cus; ++i)
+    if (counts[i]) {
+      CET_HIP(hipStreamWaitEvent(stream, pool.slot[i].done, 0));
+      busy -= pool.slot[i].cus;
+    }
+  pool.slot[pick].cus = need_cus;
   pool.slot[pick].used = true;
   pool.slot[pick].last = stream;
   *slot_out = pick;
@@ -2211,8 +2235,18 @@ static int rollout_with(const RnnModel* m, const float* x, float* out, int B, in
     if (m->device < 0 || m->device >= SPLIT_MAX_DEVICES) return CET_ERR_UNSUPPORTED;
     SplitPool& pool = g_split_pool[m->device];
     std::lock_guard<std::mutex> lock(pool.mu);  // claim, launches and event as one step (see SplitPool)
+    // CUs for every workgroup of the (largest) launch to be resident at once
+    long need = m->cus;
+    if (shared) {
+      need = (long)((B + MT - 1) / MT) * shared;
+    } else {
+      const int tiles = split_tiles(B < chunk ? B : chunk);
+      const SplitPlan plan = split_plan(m, tiles);
+      if (plan.uw) need = split_workgroups(m, tiles, plan);
+    }
+    if (need > m->cus) need = m->cus;
     int slot = -1;
-    if (const int rc = split_claim(m, pool, stream, &slot)) return rc;
+    if (const int rc = split_claim(m, pool, stream, (int)need, &slot)) return rc;
     int rc = CET_OK;
     if (shared) rc = rollout_shared(m, x, out, B, seq_len, pred_len, shared, pool.slot[slot].buf, stream);
     for (int b0 = 0; !shared && b0 < B && rc == CET_OK; b0 += chunk) {

@@ -178,7 +178,7 @@ int cet_rnn_rollout(cet_handle h, const float* x, float* out, int B, int seq_len
  * host threads: each call claims one of four exchange buffers per GPU (a call that finds all four in flight on other
  * streams queues its stream behind one of them), and behind every hidden-split launch the
  * batch-tiled kernel is launched on the same stream on stand-by; it returns at once unless the
- * exchange gave up (other work kept part of the grid from becoming resident for about a second),
+ * exchange gave up (other work kept part of the grid from becoming resident for about a tenth of a second),
  * in which case it computes that chunk. Under stream capture choice 0 uses a kernel that needs no
  * exchange and the exchanging choices return CET_ERR_UNSUPPORTED (cet_rnn_rollout_static serves captured small
  * batches). Not to be called while a rollout of the same handle runs on another thread. No

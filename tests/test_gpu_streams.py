@@ -41,10 +41,20 @@ def test_two_streams_share_the_handles():
             with torch.cuda.stream(s):
                 got[i] = work(*jobs[i])
     torch.cuda.synchronize()
-    for w, g in zip(want, got):
-        for a, b in zip(w, g):
+    for j, w, g in zip(jobs, want, got):
+        for k, (a, b) in enumerate(zip(w, g)):
             a, b = (torch.view_as_real(t) if t.is_complex() else t for t in (a, b))
-            assert torch.equal(a, b)
+            assert _same_bits(b, a, gru, j[0]) if k == 2 else torch.equal(a, b)
+
+
+def _same_bits(g, want, m, x, pred_len=5):
+    """The bits of the single-stream result -- or, should other work have kept an exchanging grid
+    off the GPU beyond its bounded wait, the bits of the stand-by launch that then recomputed the
+    rollout (the batch-tiled kernel behind a hidden-split launch, the half-tile kernel behind a
+    shared half-tile launch): correct either way, and the library promises no more."""
+    if torch.equal(g, want):
+        return True
+    return any(torch.equal(g, m.select_kernel(k).test_data(x, pred_len, "cuda")) for k in ("tiled", "half_tile"))
 
 
 def _histories(B, seed):
@@ -68,7 +78,7 @@ def test_hidden_split_rollouts_of_one_handle_overlap_on_two_streams():
     torch.cuda.synchronize()
     for i in range(2):
         for g in got[i]:
-            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+            assert torch.isfinite(g).all() and _same_bits(g, want[i], gru, xs[i])
 
 
 def test_more_streams_than_exchange_buffers():
@@ -96,7 +106,7 @@ def test_more_streams_than_exchange_buffers():
     torch.cuda.synchronize()
     for i in range(len(jobs)):
         for g in got[i]:
-            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+            assert torch.isfinite(g).all() and _same_bits(g, want[i], *jobs[i])
     for g in got_inf:
         assert torch.equal(g, want_inf)
 
@@ -137,7 +147,7 @@ def test_host_threads_claim_exchange_buffers_concurrently():
     for i in range(len(jobs)):
         assert len(got[i]) == 25
         for g in got[i]:
-            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+            assert torch.isfinite(g).all() and _same_bits(g, want[i], *jobs[i])
 
 
 def test_shared_half_tile_rollouts_overlap_and_fall_back():
@@ -158,7 +168,7 @@ def test_shared_half_tile_rollouts_overlap_and_fall_back():
     torch.cuda.synchronize()
     for i in range(len(xs)):
         for g in got[i]:
-            assert torch.isfinite(g).all() and torch.equal(g, want[i])
+            assert torch.isfinite(g).all() and _same_bits(g, want[i], gru, xs[i])
     unshared = gru.select_kernel("half_tile").test_data(xs[0], 5, "cuda")
     rescued = gru.select_kernel("half_tile_2_giveup").test_data(xs[0], 5, "cuda")
     assert torch.equal(rescued, unshared)  # the stand-by launch is the half-tile kernel with a tile per workgroup
@@ -167,7 +177,7 @@ def test_shared_half_tile_rollouts_overlap_and_fall_back():
 @pytest.mark.parametrize("name", ["GRU", "LSTM", "RNN"])
 def test_abandoned_exchange_is_recomputed_by_the_stand_by_launch(name):
     """"split_giveup" makes the hidden-split kernel abandon its exchange at the first unanswered
-    poll, as it would after a second of waiting for workgroups that other work keeps from becoming
+    poll, as it would after a tenth of a second of waiting for workgroups that other work keeps from becoming
     resident: the batch-tiled kernel launched behind it must then deliver the batch-tiled bits, for
     one launch and for a chunked batch; with a working exchange it must leave the results alone."""
     m = build_rnn(name, "tiled")
