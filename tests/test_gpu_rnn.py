@@ -401,3 +401,29 @@ def test_feature_counts_that_are_no_multiple_of_4(name, cell):
         out = m.select_kernel(variant).test_data(x, 5, "cuda").cpu().numpy()
         assert out.shape == want.shape == (20, 5, shape[0])
         assert np.abs(out - want).max() < 5e-5 * max(1.0, float(np.abs(want).max())), variant
+
+
+@pytest.mark.parametrize("name", ["GRU", "LSTM", "RNN"])
+def test_edges_of_the_call(name, oracle):
+    """What the reference's test_data takes at its edges (LocalSimulations/models/model.py:298-312,
+    373-388, 449-465): an empty batch, one sequence, one slot of history, one predicted slot, a
+    non-contiguous and a float64 input -- on every kernel, against the CPU checker."""
+    _cls, kind, F, I, H, layers = RNN_CASES[name]
+    sd = sub_dict(load_npz("rnn_ckpt.npz"), name)
+    blob = blobs.pack_rnn(sd, kind, F, I, H, layers)
+    rng = np.random.default_rng(31)
+    x = (0.6 * rng.standard_normal((37, 9, F))).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    for variant in ["auto"] + VARIANTS:
+        m = build(name, variant)
+        assert m.test_data(xt[:0], 4, "cuda").shape == (0, 4, F)
+        for xs, P in ((x[:1], 4), (x[:, :1], 3), (x, 1), (x[:5, :2], 1)):
+            want = oracle.rnn_rollout(kind, F, I, H, layers, blob, np.ascontiguousarray(xs), P)
+            got = m.test_data(torch.from_numpy(np.ascontiguousarray(xs)).cuda(), P, "cuda").cpu().numpy()
+            assert got.shape == want.shape and np.abs(got - want).max() < 1e-4 * max(1.0, float(np.abs(want).max())), (variant, xs.shape, P)
+        want = oracle.rnn_rollout(kind, F, I, H, layers, blob, np.ascontiguousarray(x[::2, 1:8]), 2)
+        strided = xt[::2, 1:8]  # neither contiguous nor at the start of its storage
+        assert not strided.is_contiguous()
+        for inp in (strided, strided.double()):
+            got = m.test_data(inp, 2, "cuda").cpu().numpy()
+            assert np.abs(got - want).max() < 1e-4 * max(1.0, float(np.abs(want).max())), variant
