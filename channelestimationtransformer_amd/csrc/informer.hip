@@ -85,7 +85,8 @@ struct KArgs {
   float* out;
   float* attn;  // nullable
   float* taps;  // nullable
-  int B;
+  int B;            // sequences of the call (the strides of attn and taps)
+  int first, last;  // sequences [first, last) are this launch's
   int enc_in, dec_in, c_out, seq_len, label_len, pred_len;
   int n_enc, distil, activation, d_layers;
   int enc_layers[8];
@@ -1512,9 +1513,9 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
   const int lane = threadIdx.x & 63;
   const int wave = WG ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
   const int R = a.region_rows;
-  const int seq = WG ? (int)blockIdx.x * WG_WAVES + wave : (int)blockIdx.x;
-  const bool valid = seq < a.B;
-  const int b = valid ? seq : a.B - 1;
+  const int seq = a.first + (WG ? (int)blockIdx.x * WG_WAVES + wave : (int)blockIdx.x);
+  const bool valid = seq < a.last;
+  const int b = valid ? seq : a.last - 1;
   float* smem = WG ? smem_all + 2 * WBLK + wave * a.wave_lds_floats : smem_all;
 #ifdef CET_PROF
   int prof_idx = 0;
@@ -1595,7 +1596,7 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
           if (a.ops[j].type == OP_LAYER) attn_all += (size_t)a.B * a.n_heads * a.ops[j].L * a.ops[j].L;
       const int seq1 = seq - WG_WAVES / 2;
       for (; i < a.n_ops; ++i)
-        run_op_partner<RM>(a.ops[i], a, cu, st, smem, ln, mem, attn_all, seq1 < a.B ? seq1 : -1, valid ? b : -1);
+        run_op_partner<RM>(a.ops[i], a, cu, st, smem, ln, mem, attn_all, seq1 < a.last ? seq1 : -1, valid ? b : -1);
     } else {
       float* partner_smem = smem + (WG_WAVES / 2) * a.wave_lds_floats;
       const int seq2 = seq + WG_WAVES / 2;
@@ -1607,7 +1608,7 @@ __global__ __launch_bounds__(WG ? 64 * WG_WAVES : 64,
       }
       for (; i < a.n_ops; ++i)
         run_op_packed<RM>(a.ops[i], a, cu, st, smem, partner_smem, R, ln, valid ? b : -1,
-                          seq2 < a.B ? seq2 : -1, x, mem);
+                          seq2 < a.last ? seq2 : -1, x, mem);
     }
   }
   tap<RM>(cu.taps, a.B, b, a.mem_rows, ln, mem);
@@ -2174,6 +2175,13 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
   a.prof = prof_dev;
 #endif
   const bool d2 = Ld > 16, m2 = a.mem_rows > 16;
+  const KArgs& a_all = a;
+  // Launches sequences [first, last) on one of the two launch shapes.
+  auto launch = [&](const bool wg, const int first, const int last) -> int {
+  KArgs a = a_all;
+  a.first = first;
+  a.last = last;
+  const int B = last - first;
   if (wg) {
     a.wave_lds_floats = (int)(wg_wave_bytes / sizeof(float));
     a.region_rows = R_wg;
@@ -2221,6 +2229,20 @@ int informer_forward(const InformerModel* m, const float* x_enc, const float* x_
     else hipLaunchKernelGGL((informer_kernel<2, 2, 2, false, 4>), grid, block, lds, stream, a);
   }
   CET_HIP(hipGetLastError());
+  return CET_OK;
+  };
+  // The automatic choice takes a batch of whole rounds of the workgroup kernel (8 sequences per CU)
+  // plus up to 2 per CU in two launches: the rounds, then the rest on the one-wave kernel (0.17 to
+  // 0.19 ms instead of another round's 0.25: 2,304 sequences 0.50 -> 0.44 ms, 4,352 0.76 -> 0.69;
+  // with 4 per CU left over the gain is gone: 5,120 sequences 0.76 -> 0.80). The launches write
+  // disjoint sequences of the same outputs.
+  const int round = WG_WAVES * m->cus;
+  if (wg && !force_wg && B % round > 0 && B % round <= 2 * m->cus) {
+    if (const int rc = launch(true, 0, B / round * round)) return rc;
+    if (const int rc = launch(false, B / round * round, B)) return rc;
+  } else if (const int rc = launch(wg, 0, B)) {
+    return rc;
+  }
 #ifdef CET_PROF
   {
     static unsigned long long h[PROF_SAMPLES * PROF_MAXM];
